@@ -1,0 +1,173 @@
+"""Compiled (separable prox-affine) forms of the benchmark problems.
+
+The reference builds these with cvxpy + its compiler (python/epopt/problems/*.py ->
+compiler/transforms/{prox,separate}.py); neither runs on python 3.  The *compiled*
+IR each problem ends up as is fixed by the prox rules and is written out in
+SURVEY.md 3.3 / 3.4b, so it is constructed directly here, with the same data recipes:
+
+  lasso        python/epopt/problems/lasso.py:8-15 + problem_util.py:9-42
+               compiled form docs/solver.rst:33-39
+  tv_1d        python/epopt/problems/tv_1d.py:5-20, compiler_test.py:51-57
+  robust_pca   python/epopt/problems/robust_pca.py:5-22
+  mnist hinge  python/epopt/functions.py:36-40, docs/notebooks/mnist.rst:118-129
+
+The RNG stream of 2016 numpy is not reproduced: same distributions, own fixed seed.
+"""
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import ir
+from .wire import ProxFunction
+
+
+def regression_data(m, n, rho=1.0, sigma=0.05, seed=0):
+    """A = randn(m,n) with unit-l2 columns, x0 sparse-uniform support (density rho) with
+    randn values, b = A x0 + sigma*randn(m).  reference problem_util.py:9-42."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    A /= np.sqrt(np.sum(A ** 2, 0))
+    if rho >= 1:
+        x0 = rng.randn(n)
+    else:
+        x0 = np.zeros(n)
+        nnz = int(round(rho * n))
+        idx = rng.choice(n, nnz, replace=False)
+        x0[idx] = rng.randn(nnz)
+    b = A.dot(x0) + sigma * rng.randn(m)
+    return A, b
+
+
+def lasso_ir(A_map, b_expr, lam, n):
+    """sum_square(A x - b) + lam*norm_1(y)  s.t.  x - y = 0   (docs/solver.rst:33-39).
+
+    `x` is the copy the separate pass makes for the first function sharing the variable
+    (compiler/transforms/separate.py:64-85)."""
+    x = ir.variable(n, 1, "var:x")
+    y = ir.variable(n, 1, "separate:var:x:norm_1")
+    m = A_map.m
+    f0 = ir.prox(ProxFunction.SUM_SQUARE,
+                 ir.add(ir.linear_map(A_map, x),
+                        ir.linear_map(ir.scalar(-1, m), b_expr)),
+                 alpha=1.0)
+    f1 = ir.prox(ProxFunction.NORM_1, y, alpha=lam)
+    c = ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, n), y)))
+    return ir.Problem([f0, f1], [c])
+
+
+def lasso(m, n, rho=1.0, seed=0):
+    A, b = regression_data(m, n, rho=rho, seed=seed)
+    lam = 0.5 * np.abs(A.T.dot(b)).max()
+    prob = lasso_ir(ir.dense_matrix(A), ir.constant(b), lam, n)
+    return prob, dict(A=A, b=b, lam=lam)
+
+
+def lasso_objective(A, b, lam, x):
+    r = A.dot(x) - b
+    return float(r.dot(r) + lam * np.abs(x).sum())
+
+
+def tv_1d_data(n, seed=0):
+    """reference tv_1d.py:5-17; the piecewise-constant signal is built from a difference
+    array + prefix sum instead of the O(k n) python loop."""
+    rng = np.random.RandomState(seed)
+    k = max(int(np.sqrt(n) / 2), 1)
+    idxs = rng.randint(0, n, (k, 2))
+    idxs.sort()
+    steps = 10 * (rng.rand(k) - 0.5)
+    diff = np.zeros(n + 1)
+    np.add.at(diff, idxs[:, 0], steps)
+    np.add.at(diff, idxs[:, 1], -steps)
+    x0 = 1.0 + np.cumsum(diff[:n])
+    b = x0 + rng.randn(n)
+    return b, float(np.sqrt(n))
+
+
+def tv_1d(n, seed=0):
+    """0.5*sum_square(x' - b) + lam*total_variation_1d(x)  s.t.  x' - x = 0."""
+    b, lam = tv_1d_data(n, seed)
+    xp = ir.variable(n, 1, "separate:var:x:sum_square")
+    x = ir.variable(n, 1, "var:x")
+    f0 = ir.prox(ProxFunction.TOTAL_VARIATION_1D, x, alpha=lam)
+    f1 = ir.prox(ProxFunction.SUM_SQUARE,
+                 ir.add(xp, ir.linear_map(ir.scalar(-1, n), ir.constant(b))), alpha=0.5)
+    c = ir.zero(ir.add(xp, ir.linear_map(ir.scalar(-1, n), x)))
+    return ir.Problem([f0, f1], [c]), dict(b=b, lam=lam)
+
+
+def tv_1d_objective(b, lam, x):
+    return float(0.5 * np.sum((x - b) ** 2) + lam * np.abs(np.diff(x)).sum())
+
+
+def tv_1d_prox_expr(n, lam_alpha=1.0):
+    """Single TOTAL_VARIATION_1D term for `eval_prox` (prox_test.py:209 cp.tv(x))."""
+    x = ir.variable(n, 1, "var:x")
+    return ir.prox(ProxFunction.TOTAL_VARIATION_1D, x, alpha=lam_alpha)
+
+
+def robust_pca_data(n, r=10, density=0.1, seed=0):
+    rng = np.random.RandomState(seed)
+    L0 = rng.randn(n, r).dot(rng.randn(r, n))
+    S0 = sp.rand(n, n, density, random_state=rng)
+    S0.data = 10 * rng.randn(len(S0.data))
+    return np.asarray(L0 + S0.toarray())
+
+
+def robust_pca(n, r=10, density=0.1, seed=0, lam=0.1):
+    """norm_nuclear(L) + lam*norm_1(S)  s.t.  L + S - M = 0  (SURVEY 3.4b)."""
+    M = robust_pca_data(n, r, density, seed)
+    L = ir.variable(n, n, "var:L")
+    S = ir.variable(n, n, "var:S")
+    f0 = ir.prox(ProxFunction.NORM_NUCLEAR, L, alpha=1.0)
+    f1 = ir.prox(ProxFunction.NORM_1, S, alpha=lam)
+    c = ir.zero(ir.add(L, S, ir.linear_map(ir.scalar(-1, n * n), ir.constant(M.reshape(-1, 1, order="F")))))
+    return ir.Problem([f0, f1], [c]), dict(M=M, lam=lam)
+
+
+def robust_pca_objective(lam, Lm, Sm):
+    return float(np.linalg.svd(Lm, compute_uv=False).sum() + lam * np.abs(Sm).sum())
+
+
+def multiclass_hinge_data(m, nf, k, seed=0):
+    rng = np.random.RandomState(seed)
+    X = rng.rand(m, nf)
+    y = rng.randint(0, k, m)
+    Y = np.zeros((m, k))
+    Y[np.arange(m), y] = 1.0
+    return X, Y
+
+
+def multiclass_hinge(X, Y, lam):
+    """Compiled form of sum_i max_j (X Theta + 1 - Y)_ij - <X^T Y, Theta> + lam||Theta||^2
+    (functions.py:36-40) as printed at docs/notebooks/mnist.rst:118-129:
+
+      affine(1^T t) + non_negative(y) + affine(-<X^T Y, Z>) + sum_square(W)[lam]
+      zero(kron(1_k, I_m) t - (kron(I_k, X) W + 1 - vec(Y)) - y),   zero(Z - W)
+    """
+    m, nf = X.shape
+    k = Y.shape[1]
+    t = ir.variable(m, 1, "max_entries:t")
+    y = ir.variable(m * k, 1, "non_negative:y")
+    Z = ir.variable(nf * k, 1, "separate:var:Theta:affine")
+    W = ir.variable(nf * k, 1, "var:Theta")
+    f0 = ir.prox(ProxFunction.AFFINE,
+                 ir.linear_map(ir.dense_matrix(np.ones((1, m))), t), alpha=1.0)
+    f1 = ir.prox(ProxFunction.NON_NEGATIVE, y, alpha=1.0)
+    c_vec = -(X.T.dot(Y)).reshape(1, -1, order="F")
+    f2 = ir.prox(ProxFunction.AFFINE, ir.linear_map(ir.dense_matrix(c_vec), Z), alpha=1.0)
+    f3 = ir.prox(ProxFunction.SUM_SQUARE, W, alpha=lam)
+    ones_k = ir.dense_matrix(np.ones((1, k)))
+    lift_t = ir.kronecker_product(ir.transpose(ones_k), ir.identity(m))  # t 1^T
+    XW = ir.linear_map(ir.kronecker_product(ir.identity(k), ir.dense_matrix(X)), W)
+    const = ir.constant((1.0 - Y).reshape(-1, 1, order="F"))
+    inner = ir.add(XW, const)
+    c0 = ir.zero(ir.add(ir.linear_map(lift_t, t),
+                        ir.linear_map(ir.scalar(-1, m * k), inner),
+                        ir.linear_map(ir.scalar(-1, m * k), y)))
+    c1 = ir.zero(ir.add(Z, ir.linear_map(ir.scalar(-1, nf * k), W)))
+    return ir.Problem([f0, f1, f2, f3], [c0, c1]), dict(X=X, Y=Y, lam=lam)
+
+
+def multiclass_hinge_objective(X, Y, lam, Theta):
+    S = X.dot(Theta) + 1 - Y
+    return float(S.max(axis=1).sum() - np.sum(X.T.dot(Y) * Theta) + lam * np.sum(Theta ** 2))
