@@ -1,0 +1,372 @@
+#include "admm.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+
+#include "kernels.h"
+
+namespace eps {
+
+namespace {
+
+double Now() {
+  using clock = std::chrono::steady_clock;
+  return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+Solver::Solver(pb::Problem problem, std::shared_ptr<DataMap> data, pb::SolverParams params)
+    : problem_(std::move(problem)), data_(std::move(data)), params_(params) {}
+
+void Solver::LogStatus() {  // reference prox_admm.cc:219-230
+  if (!params_.verbose || !log_) return;
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "iter=%d residuals primal=%.2e [%.2e] dual=%.2e [%.2e]",
+                status_.num_iterations, status_.r_norm, status_.epsilon_primal, status_.s_norm,
+                status_.epsilon_dual);
+  log_(buf);
+}
+
+void Solver::FinishResiduals(double r, double s, double eps_pri, double eps_dual) {
+  status_.r_norm = r;
+  status_.s_norm = s;
+  status_.epsilon_primal = eps_pri;
+  status_.epsilon_dual = eps_dual;
+  if (r <= eps_pri && s <= eps_dual && !params_.ignore_stopping_criteria)
+    status_.state = pb::SolverStatus::OPTIMAL;
+  else
+    status_.state = pb::SolverStatus::RUNNING;
+  status_.num_iterations = iter_;
+}
+
+int Solver::Run(int max_sweeps) {
+  EPS_CHECK_MSG(initialized_, "Solver::Run before Init");
+  SetCurrentDType(data_->dtype());
+  const double t0 = Now();
+  int done = 0;
+  while (!finished_ && iter_ < params_.max_iterations && (max_sweeps < 0 || done < max_sweeps)) {
+    Sweep();
+    ++done;
+    if (iter_ % params_.epoch_iterations == 0) {
+      ComputeResiduals();
+      if (status_.state == pb::SolverStatus::OPTIMAL) {
+        finished_ = true;
+        break;
+      }
+    }
+    if (iter_ % params_.log_iterations == 0) LogStatus();
+    ++iter_;
+  }
+  if (!finished_ && iter_ == params_.max_iterations) {
+    ComputeResiduals();
+    status_.state = pb::SolverStatus::MAX_ITERATIONS_REACHED;
+    finished_ = true;
+  }
+  Runtime::Get().Sync();
+  loop_seconds_ += Now() - t0;
+  if (finished_) LogStatus();
+  status_.init_time = init_seconds_;
+  status_.total_time = init_seconds_ + loop_seconds_;
+  return done;
+}
+
+void Solver::Solve() {
+  const double t0 = Now();
+  Init();
+  Runtime::Get().Sync();
+  init_seconds_ = Now() - t0;
+  Run(-1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ProxADMMSolver (reference algorithms/prox_admm.cc)
+// ---------------------------------------------------------------------------------------------------
+
+class ProxADMMSolver final : public Solver {
+ public:
+  using Solver::Solver;
+
+  void Init() override {  // :110-129
+    SetCurrentDType(data_->dtype());
+    const double t0 = Now();
+    InitConstraints();
+    InitProxOperators();
+    if (!params_.warm_start || !vars_initialized_) {
+      InitVariables();
+      vars_initialized_ = true;
+    }
+    iter_ = 0;
+    finished_ = false;
+    status_ = pb::SolverStatus();
+    initialized_ = true;
+    if (params_.verbose && log_) {
+      char buf[128];
+      std::snprintf(buf, sizeof(buf), "constraints, m = %lld, variables, n = %lld",
+                    static_cast<long long>(m_), static_cast<long long>(n_));
+      log_(buf);
+    }
+    Runtime::Get().Sync();
+    init_seconds_ = Now() - t0;
+  }
+
+  BlockVector GetSolution() override {  // :171-176
+    BlockVector r;
+    for (int i = 0; i < N_; ++i) r += x_[i];
+    return r;
+  }
+
+ protected:
+  void InitConstraints() {  // :25-43
+    A_ = BlockMatrix();
+    b_ = BlockVector();
+    for (size_t i = 0; i < problem_.constraint.size(); ++i) {
+      const pb::Expression& constr = problem_.constraint[i];
+      EPS_CHECK_MSG(constr.expression_type == pb::Expression::INDICATOR, "constraint is not an indicator");
+      EPS_CHECK_MSG(constr.cone_type == 1, "constraint cone is not ZERO");
+      EPS_CHECK(constr.arg.size() == 1);
+      affine::BuildAffineOperator(constr.arg[0], data_.get(), affine::constraint_key(i), &A_, &b_);
+    }
+    AT_ = A_.Transpose();
+    m_ = A_.m();
+    n_ = A_.n();
+  }
+
+  void InitProxOperators() {  // :45-94
+    EPS_CHECK_MSG(problem_.objective.expression_type == pb::Expression::ADD, "objective is not ADD");
+    N_ = static_cast<int>(problem_.objective.arg.size());
+    EPS_CHECK_MSG(params_.rho == 1, "rho != 1 is not supported (reference prox_admm.cc:50)");
+    const double sqrt_rho = std::sqrt(params_.rho);
+    prox_.clear();
+    AiT_.clear();
+    std::set<std::string> constr_vars = A_.col_keys();
+    for (int i = 0; i < N_; ++i) {
+      const pb::Expression& f_expr = problem_.objective.arg[i];
+      EPS_CHECK_MSG(f_expr.expression_type == pb::Expression::PROX_FUNCTION,
+                    "objective term " << i << " is not a PROX_FUNCTION");
+      AffineOperator H;
+      for (size_t k = 0; k < f_expr.arg.size(); ++k)
+        affine::BuildAffineOperator(f_expr.arg[k], data_.get(), affine::arg_key(k), &H.A, &H.b);
+      AffineOperator A;
+      std::map<std::string, const pb::Expression*> vars;
+      GetVariables(f_expr, &vars);
+      for (const auto& var : vars) {
+        if (constr_vars.find(var.first) == constr_vars.end()) continue;
+        for (const auto& it : A_.col(var.first)) A.A(it.first, var.first) = sqrt_rho * it.second;
+      }
+      prox_.emplace_back(CreateProxOperator(f_expr.prox_function.prox_function_type,
+                                            f_expr.prox_function.epigraph));
+      prox_.back()->Init(ProxOperatorArg(f_expr.prox_function, data_.get(), H, A));
+      AiT_.push_back(A.A.Transpose());
+    }
+  }
+
+  void InitVariables() {  // :96-108
+    x_.assign(N_, BlockVector());
+    y_.assign(N_, BlockVector());
+    u_ = BlockVector();
+    for (size_t i = 0; i < problem_.constraint.size(); ++i) {
+      u_.Set(affine::constraint_key(i),
+             DVec::Zeros(GetDimension(problem_.constraint[i].arg[0]), data_->dtype()));
+    }
+  }
+
+  void Sweep() override {  // :135-147
+    y_prev_ = y_;  // shallow: blocks are replaced, never mutated, below
+    u_ -= b_;
+    for (int i = 0; i < N_; ++i) u_ -= y_[i];
+    for (int i = 0; i < N_; ++i) {
+      u_ += y_[i];
+      x_[i] = prox_[i]->Apply(u_);
+      y_[i] = A_ * x_[i];
+      u_ -= y_[i];
+    }
+  }
+
+  void ComputeResiduals() override {  // :178-217
+    Runtime& rt = Runtime::Get();
+    rt.ResetSlots();
+    const int s_b = b_.NormSqAsync();
+    std::vector<int> s_Ax(N_);
+    BlockVector Ax_b = b_;
+    for (int i = 0; i < N_; ++i) {
+      // A_*x_[i] is y_[i], computed by the sweep (the reference recomputes it, :186)
+      s_Ax[i] = y_[i].NormSqAsync();
+      Ax_b += y_[i];
+    }
+    const int s_r = Ax_b.NormSqAsync();
+    std::vector<int> s_s;
+    BlockVector Ax_diff;
+    for (int i = N_ - 2; i >= 0; --i) {
+      Ax_diff += y_[i + 1] - y_prev_[i + 1];
+      s_s.push_back((AiT_[i] * Ax_diff).NormSqAsync());
+    }
+    const int s_u = (AT_ * u_).NormSqAsync();
+    rt.FetchSlots();
+
+    double max_norm = std::sqrt(rt.SlotValue(s_b));
+    for (int i = 0; i < N_; ++i) max_norm = std::fmax(max_norm, std::sqrt(rt.SlotValue(s_Ax[i])));
+    double s2 = 0;
+    for (int s : s_s) {
+      const double si = std::sqrt(rt.SlotValue(s));
+      s2 += si * si;
+    }
+    const double rho = params_.rho;
+    FinishResiduals(std::sqrt(rt.SlotValue(s_r)), rho * std::sqrt(s2),
+                    params_.abs_tol * std::sqrt(static_cast<double>(m_)) + params_.rel_tol * max_norm,
+                    params_.abs_tol * std::sqrt(static_cast<double>(n_)) +
+                        params_.rel_tol * rho * std::sqrt(rt.SlotValue(s_u)));
+  }
+
+ private:
+  int64_t m_ = 0, n_ = 0;
+  int N_ = 0;
+  bool vars_initialized_ = false;
+  BlockMatrix A_, AT_;
+  BlockVector b_;
+  std::vector<BlockMatrix> AiT_;
+  std::vector<std::unique_ptr<ProxOperator>> prox_;
+  BlockVector u_;
+  std::vector<BlockVector> x_, y_, y_prev_;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// ProxADMMTwoBlockSolver (reference algorithms/prox_admm_two_block.cc)
+// ---------------------------------------------------------------------------------------------------
+
+class ProxADMMTwoBlockSolver final : public Solver {
+ public:
+  using Solver::Solver;
+
+  void Init() override {  // :21-94
+    SetCurrentDType(data_->dtype());
+    const double t0 = Now();
+    const double sqrt_rho = std::sqrt(params_.rho);
+    const DType dt = data_->dtype();
+    AffineOperator H, A;
+    BlockVector z0;
+    for (size_t i = 0; i < problem_.constraint.size(); ++i) {
+      const pb::Expression& constr = problem_.constraint[i];
+      EPS_CHECK_MSG(constr.expression_type == pb::Expression::INDICATOR, "constraint is not an indicator");
+      EPS_CHECK_MSG(constr.cone_type == 1, "constraint cone is not ZERO");
+      EPS_CHECK(constr.arg.size() == 1);
+      affine::BuildAffineOperator(constr.arg[0], data_.get(), affine::constraint_key(i), &H.A, &H.b);
+      std::map<std::string, const pb::Expression*> vars;
+      GetVariables(constr, &vars);
+      for (const auto& var : vars) {
+        const int64_t dim = GetDimension(*var.second);
+        A.A(var.first, var.first) = sqrt_rho * LinearMap::Identity(dim);
+        z0.Set(var.first, DVec::Zeros(dim, dt));
+      }
+    }
+    constr_prox_ = CreateProxOperator(pb::ProxFunction::ZERO, false);
+    zero_f_ = pb::ProxFunction();
+    constr_prox_->Init(ProxOperatorArg(zero_f_, data_.get(), H, A));
+    m_ = H.A.m();
+    n_ = H.A.n();
+
+    EPS_CHECK_MSG(problem_.objective.expression_type == pb::Expression::ADD, "objective is not ADD");
+    N_ = static_cast<int>(problem_.objective.arg.size());
+    prox_.clear();
+    for (int i = 0; i < N_; ++i) {
+      const pb::Expression& f_expr = problem_.objective.arg[i];
+      EPS_CHECK_MSG(f_expr.expression_type == pb::Expression::PROX_FUNCTION,
+                    "objective term " << i << " is not a PROX_FUNCTION");
+      AffineOperator Hi, Ai;
+      for (size_t k = 0; k < f_expr.arg.size(); ++k)
+        affine::BuildAffineOperator(f_expr.arg[k], data_.get(), affine::arg_key(k), &Hi.A, &Hi.b);
+      std::map<std::string, const pb::Expression*> vars;
+      GetVariables(f_expr, &vars);
+      for (const auto& var : vars)
+        Ai.A(var.first, var.first) = sqrt_rho * LinearMap::Identity(GetDimension(*var.second));
+      prox_.emplace_back(CreateProxOperator(f_expr.prox_function.prox_function_type,
+                                            f_expr.prox_function.epigraph));
+      prox_.back()->Init(ProxOperatorArg(f_expr.prox_function, data_.get(), Hi, Ai));
+    }
+    if (!params_.warm_start || !vars_initialized_) {
+      z_ = z0;
+      u_ = BlockVector();
+      x_ = BlockVector();
+      vars_initialized_ = true;
+    }
+    iter_ = 0;
+    finished_ = false;
+    status_ = pb::SolverStatus();
+    initialized_ = true;
+    Runtime::Get().Sync();
+    init_seconds_ = Now() - t0;
+  }
+
+  BlockVector GetSolution() override { return x_; }
+
+ protected:
+  void Sweep() override {  // :97-112
+    z_prev_ = z_;
+    BlockVector zu = z_ - u_;
+    x_ = BlockVector();
+    for (int i = 0; i < N_; ++i) x_ += prox_[i]->Apply(zu);
+    z_ = constr_prox_->Apply(x_ + u_);
+    u_ += x_ - z_;
+  }
+
+  void ComputeResiduals() override {  // :135-156
+    Runtime& rt = Runtime::Get();
+    rt.ResetSlots();
+    const int s_r = DiffNormSqAsync(x_, z_);
+    const int s_s = DiffNormSqAsync(z_, z_prev_);
+    const int s_x = x_.NormSqAsync();
+    const int s_z = z_.NormSqAsync();
+    const int s_u = u_.NormSqAsync();
+    rt.FetchSlots();
+    const double rho = params_.rho;
+    const double sq_n = std::sqrt(static_cast<double>(n_));
+    FinishResiduals(std::sqrt(rt.SlotValue(s_r)), rho * std::sqrt(rt.SlotValue(s_s)),
+                    params_.abs_tol * sq_n + params_.rel_tol * std::fmax(std::sqrt(rt.SlotValue(s_x)),
+                                                                         std::sqrt(rt.SlotValue(s_z))),
+                    params_.abs_tol * sq_n + params_.rel_tol * rho * std::sqrt(rt.SlotValue(s_u)));
+  }
+
+ private:
+  int64_t m_ = 0, n_ = 0;
+  int N_ = 0;
+  bool vars_initialized_ = false;
+  pb::ProxFunction zero_f_;
+  std::vector<std::unique_ptr<ProxOperator>> prox_;
+  std::unique_ptr<ProxOperator> constr_prox_;
+  BlockVector x_, z_, u_, z_prev_;
+};
+
+std::unique_ptr<Solver> CreateSolver(pb::Problem problem, std::shared_ptr<DataMap> data,
+                                     pb::SolverParams params) {  // solvemodule.cc:74-87
+  if (params.solver == pb::SolverParams::PROX_ADMM)
+    return std::unique_ptr<Solver>(new ProxADMMSolver(std::move(problem), std::move(data), params));
+  if (params.solver == pb::SolverParams::PROX_ADMM_TWO_BLOCK)
+    return std::unique_ptr<Solver>(
+        new ProxADMMTwoBlockSolver(std::move(problem), std::move(data), params));
+  EPS_FATAL("Unknown solver: " << params.solver);
+}
+
+BlockVector EvalProx(const pb::Expression& f_expr, double lambda, DataMap* data,
+                     const BlockVector& v_in) {  // solvemodule.cc:189-242
+  EPS_CHECK_MSG(f_expr.expression_type == pb::Expression::PROX_FUNCTION,
+                "eval_prox: expression is not a PROX_FUNCTION");
+  SetCurrentDType(data->dtype());
+  AffineOperator H, A;
+  for (size_t i = 0; i < f_expr.arg.size(); ++i)
+    affine::BuildAffineOperator(f_expr.arg[i], data, affine::arg_key(i), &H.A, &H.b);
+  std::map<std::string, const pb::Expression*> vars;
+  GetVariables(f_expr, &vars);
+  int i = 0;
+  for (const auto& var : vars) {
+    A.A(affine::constraint_key(i++), var.first) =
+        (1 / std::sqrt(lambda)) * LinearMap::Identity(GetDimension(*var.second));
+  }
+  BlockVector v = A.A * v_in;
+  std::unique_ptr<ProxOperator> op = CreateProxOperator(f_expr.prox_function.prox_function_type,
+                                                        f_expr.prox_function.epigraph);
+  op->Init(ProxOperatorArg(f_expr.prox_function, data, H, A));
+  return op->Apply(v);
+}
+
+}  // namespace eps

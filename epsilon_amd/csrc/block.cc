@@ -1,0 +1,399 @@
+#include "block.h"
+
+#include <cmath>
+#include <limits>
+#include <sstream>
+#include <unordered_set>
+
+#include "kernels.h"
+
+namespace eps {
+
+// ---- BlockVector (reference vector/block_vector.cc) -------------------------------------------------
+
+const DVec& BlockVector::operator()(const std::string& key) const {
+  auto it = data_.find(key);
+  EPS_CHECK_MSG(it != data_.end(), key << " not in BlockVector");
+  return it->second;
+}
+
+DVec& BlockVector::Mutable(const std::string& key) {
+  auto it = data_.find(key);
+  EPS_CHECK_MSG(it != data_.end(), key << " not in BlockVector");
+  DVec& v = it->second;
+  if (v.buf && (v.buf.use_count() > 1 || !v.buf->owned)) v = v.Clone();
+  return v;
+}
+
+std::set<std::string> BlockVector::keys() const {
+  std::set<std::string> r;
+  for (const auto& kv : data_) r.insert(kv.first);
+  return r;
+}
+
+int64_t BlockVector::n() const {
+  int64_t n = 0;
+  for (const auto& kv : data_) n += kv.second.n;
+  return n;
+}
+
+void BlockVector::InsertOrAdd(const std::string& key, const DVec& value, double alpha) {
+  auto it = data_.find(key);
+  if (it == data_.end()) {  // block_vector.cc:44-49
+    if (alpha == 1.0) {
+      data_[key] = value;  // shared, copy-on-write protects it
+    } else {
+      DVec v = DVec::Empty(value.n, value.dt);
+      k::Axpby(v, alpha, value, 0.0);
+      data_[key] = v;
+    }
+    return;
+  }
+  EPS_CHECK_MSG(it->second.n == value.n, "block '" << key << "' has " << it->second.n
+                                                   << " entries, adding " << value.n);
+  // `value` may share the buffer of this block; Mutable() then clones, value stays valid
+  DVec val = value;
+  k::Axpby(Mutable(key), alpha, val, 1.0);
+}
+
+void BlockVector::InsertOrAddApply(const std::string& key, const LinearMapImpl& A, const DVec& x,
+                                   double alpha) {
+  auto it = data_.find(key);
+  if (it == data_.end()) {
+    DVec y = DVec::Empty(A.m(), x.dt);
+    A.Apply(alpha, x, 0.0, y);
+    data_[key] = y;
+    return;
+  }
+  DVec xv = x;
+  A.Apply(alpha, xv, 1.0, Mutable(key));
+}
+
+BlockVector& BlockVector::operator+=(const BlockVector& rhs) {
+  for (const auto& kv : rhs.data_) InsertOrAdd(kv.first, kv.second, 1.0);
+  return *this;
+}
+
+BlockVector& BlockVector::operator-=(const BlockVector& rhs) {
+  for (const auto& kv : rhs.data_) InsertOrAdd(kv.first, kv.second, -1.0);
+  return *this;
+}
+
+BlockVector& BlockVector::operator*=(double alpha) {
+  for (auto& kv : data_) {
+    DVec& v = Mutable(kv.first);
+    k::Axpby(v, alpha, v, 0.0);
+  }
+  return *this;
+}
+
+BlockVector BlockVector::Select(const std::set<std::string>& keys) const {
+  BlockVector r;
+  for (const auto& key : keys) {
+    auto it = data_.find(key);
+    if (it != data_.end()) r.data_.insert(*it);
+  }
+  return r;
+}
+
+int BlockVector::NormSqAsync() const {
+  Runtime& rt = Runtime::Get();
+  int s = rt.NewSlot();
+  bool first = true;
+  for (const auto& kv : data_) {
+    if (kv.second.n == 0) continue;
+    k::SumSq(kv.second, rt.SlotPtr(s), !first);
+    first = false;
+  }
+  if (first) {
+    EPS_HIP(hipMemsetAsync(rt.SlotPtr(s), 0, sizeof(double), rt.stream()));
+  }
+  return s;
+}
+
+double BlockVector::norm() const {
+  Runtime& rt = Runtime::Get();
+  rt.ResetSlots();
+  int s = NormSqAsync();
+  rt.FetchSlots();
+  return std::sqrt(rt.SlotValue(s));
+}
+
+int DiffNormSqAsync(const BlockVector& a, const BlockVector& b) {
+  Runtime& rt = Runtime::Get();
+  int s = rt.NewSlot();
+  bool first = true;
+  std::set<std::string> keys = a.keys();
+  for (const auto& key : b.keys()) keys.insert(key);
+  for (const auto& key : keys) {
+    if (a.has_key(key) && b.has_key(key)) {
+      if (a(key).n == 0) continue;
+      k::SumSqDiff(a(key), b(key), rt.SlotPtr(s), !first);
+    } else {
+      const DVec& v = a.has_key(key) ? a(key) : b(key);
+      if (v.n == 0) continue;
+      k::SumSq(v, rt.SlotPtr(s), !first);
+    }
+    first = false;
+  }
+  if (first) EPS_HIP(hipMemsetAsync(rt.SlotPtr(s), 0, sizeof(double), rt.stream()));
+  return s;
+}
+
+BlockVector operator+(BlockVector lhs, const BlockVector& rhs) {
+  lhs += rhs;
+  return lhs;
+}
+BlockVector operator-(BlockVector lhs, const BlockVector& rhs) {
+  lhs -= rhs;
+  return lhs;
+}
+BlockVector operator*(double alpha, BlockVector x) {
+  x *= alpha;
+  return x;
+}
+
+// ---- BlockMatrix (reference vector/block_matrix.cc) -------------------------------------------------
+
+const LinearMap& BlockMatrix::operator()(const std::string& row, const std::string& col) const {
+  auto c = data_.find(col);
+  EPS_CHECK_MSG(c != data_.end(), "column: " << col << " not found");
+  auto r = c->second.find(row);
+  EPS_CHECK_MSG(r != c->second.end(), "row: " << row << " not found");
+  return r->second;
+}
+
+bool BlockMatrix::has_key(const std::string& row, const std::string& col) const {
+  auto c = data_.find(col);
+  if (c == data_.end()) return false;
+  return c->second.find(row) != c->second.end();
+}
+
+BlockMatrix BlockMatrix::Transpose() const {
+  BlockMatrix t;
+  for (const auto& c : data_)
+    for (const auto& r : c.second) t.InsertOrAdd(c.first, r.first, r.second.Transpose());
+  return t;
+}
+
+BlockMatrix BlockMatrix::Inverse() const {
+  EPS_CHECK_MSG(m() == n(), "Inverting non square matrix");
+  std::set<std::string> seen;
+  for (const auto& c : data_) {
+    EPS_CHECK_MSG(c.second.size() == 1, "Unable to invert matrix\n" << DebugString());
+    const std::string& row = c.second.begin()->first;
+    EPS_CHECK_MSG(seen.insert(row).second, "Unable to invert matrix\n" << DebugString());
+  }
+  BlockMatrix inv;
+  for (const auto& c : data_) {
+    const std::string& row = c.second.begin()->first;
+    inv.InsertOrAdd(c.first, row, c.second.begin()->second.Inverse());
+  }
+  return inv;
+}
+
+BlockMatrix BlockMatrix::LeftIdentity() const {
+  BlockMatrix C;
+  for (const auto& c : data_)
+    for (const auto& r : c.second)
+      if (C.data_.find(r.first) == C.data_.end())
+        C.InsertOrAdd(r.first, r.first, LinearMap::Identity(r.second.impl().m()));
+  return C;
+}
+
+BlockMatrix BlockMatrix::RightIdentity() const {
+  BlockMatrix C;
+  for (const auto& c : data_) {
+    EPS_CHECK(!c.second.empty());
+    C.InsertOrAdd(c.first, c.first, LinearMap::Identity(c.second.begin()->second.impl().n()));
+  }
+  return C;
+}
+
+BlockMatrix operator*(const BlockMatrix& A, const BlockMatrix& B) {  // block_matrix.cc:102-127
+  BlockMatrix C;
+  for (const auto& bcol : B.data_) {
+    for (const auto& b : bcol.second) {
+      auto acol = A.data_.find(b.first);
+      if (acol == A.data_.end()) continue;
+      for (const auto& a : acol->second) C.InsertOrAdd(a.first, bcol.first, a.second * b.second);
+    }
+  }
+  return C;
+}
+
+BlockMatrix operator+(const BlockMatrix& A, const BlockMatrix& B) {
+  BlockMatrix C = A;
+  for (const auto& c : B.data_)
+    for (const auto& r : c.second) C.InsertOrAdd(r.first, c.first, r.second);
+  return C;
+}
+
+BlockMatrix operator-(const BlockMatrix& A, const BlockMatrix& B) { return A + (-1.0) * B; }
+
+BlockMatrix operator*(double alpha, const BlockMatrix& A) {
+  BlockMatrix C;
+  for (const auto& c : A.data_)
+    for (const auto& r : c.second) C.InsertOrAdd(r.first, c.first, alpha * r.second);
+  return C;
+}
+
+BlockVector operator*(const BlockMatrix& A, const BlockVector& x) {  // block_matrix.cc:155-168
+  BlockVector y;
+  for (const auto& xk : x.data()) {
+    auto col = A.data_.find(xk.first);
+    if (col == A.data_.end()) continue;
+    for (const auto& blk : col->second) y.InsertOrAddApply(blk.first, blk.second.impl(), xk.second);
+  }
+  return y;
+}
+
+void BlockMatrix::InsertOrAdd(const std::string& row, const std::string& col, LinearMap value) {
+  auto res = data_[col].insert(std::make_pair(row, value));
+  if (!res.second) res.first->second += value;
+}
+
+int64_t BlockMatrix::m() const {
+  std::unordered_set<std::string> seen;
+  int64_t m = 0;
+  for (const auto& c : data_)
+    for (const auto& r : c.second)
+      if (seen.insert(r.first).second) m += r.second.impl().m();
+  return m;
+}
+
+int64_t BlockMatrix::n() const {
+  int64_t n = 0;
+  for (const auto& c : data_) n += c.second.begin()->second.impl().n();
+  return n;
+}
+
+std::set<std::string> BlockMatrix::row_keys() const {
+  std::set<std::string> r;
+  for (const auto& c : data_)
+    for (const auto& b : c.second) r.insert(b.first);
+  return r;
+}
+
+std::set<std::string> BlockMatrix::col_keys() const {
+  std::set<std::string> r;
+  for (const auto& c : data_) r.insert(c.first);
+  return r;
+}
+
+const std::map<std::string, LinearMap>& BlockMatrix::col(const std::string& col_key) const {
+  auto it = data_.find(col_key);
+  EPS_CHECK_MSG(it != data_.end(), "column " << col_key << " not found");
+  return it->second;
+}
+
+std::string BlockMatrix::DebugString() const {
+  std::ostringstream os;
+  os << "block matrix " << m() << " x " << n();
+  for (const auto& c : data_)
+    for (const auto& r : c.second)
+      os << "\n(" << r.first << ", " << c.first << ")\n" << r.second.impl().DebugString();
+  return os.str();
+}
+
+void BlockMatrix::Remove(const std::string& row, const std::string& col) {
+  auto c = data_.find(col);
+  EPS_CHECK(c != data_.end());
+  auto r = c->second.find(row);
+  EPS_CHECK(r != c->second.end());
+  c->second.erase(r);
+  if (c->second.empty()) data_.erase(c);
+}
+
+// ---- BlockCholesky (reference vector/block_cholesky.cc) ---------------------------------------------
+
+static const uint64_t kFillMax = std::numeric_limits<uint64_t>::max();
+
+uint64_t ComputeFill(const BlockMatrix& A, const std::string& k) {  // :11-48
+  std::set<std::string> keys;
+  bool has_diagonal = false;
+  for (const auto& it : A.col(k)) {
+    if (k == it.first) has_diagonal = true;
+    else keys.insert(it.first);
+  }
+  if (!has_diagonal) return kFillMax;
+  uint64_t fill = 0;
+  for (const std::string& i : keys) {
+    ImplType aik = ComputeType(A(i, k).impl().type(), A(k, k).impl().type());
+    for (const std::string& j : keys) {
+      ImplType type = ComputeType(aik, A(j, k).impl().type());
+      fill += Nonzeros(type, A(i, k).impl().m(), A(j, k).impl().m());
+    }
+  }
+  return fill;
+}
+
+std::string NextKey(const BlockMatrix& A) {  // :51-64
+  std::string best_key;
+  uint64_t best_fill = kFillMax;
+  for (const std::string& key : A.col_keys()) {
+    uint64_t fill = ComputeFill(A, key);
+    if (fill < best_fill) {
+      best_key = key;
+      best_fill = fill;
+    }
+  }
+  EPS_CHECK_MSG(best_fill != kFillMax, "block LDL: no key with a diagonal block\n"
+                                           << A.DebugString());
+  return best_key;
+}
+
+static BlockMatrix RemoveKey(BlockMatrix* A, const std::string& key) {  // :68-83
+  BlockMatrix V;
+  std::vector<std::pair<std::string, std::string>> to_remove;
+  for (const auto& it : A->col(key)) {
+    to_remove.push_back(std::make_pair(it.first, key));
+    if (key != it.first) {
+      to_remove.push_back(std::make_pair(key, it.first));
+      V(it.first, key) = it.second;
+    }
+  }
+  for (const auto& rc : to_remove) A->Remove(rc.first, rc.second);
+  return V;
+}
+
+BlockVector ForwardSub(const BlockMatrix& L, const std::vector<std::string>& keys, BlockVector b) {
+  for (auto j = keys.begin(); j != keys.end(); ++j) {  // :86-100
+    if (!b.has_key(*j)) continue;
+    DVec bj = b(*j);
+    for (auto i = j + 1; i != keys.end(); ++i)
+      if (L.has_key(*i, *j)) b.InsertOrAddApply(*i, L(*i, *j).impl(), bj, -1.0);
+  }
+  return b;
+}
+
+BlockVector BackSub(const BlockMatrix& LT, const std::vector<std::string>& keys, BlockVector b) {
+  for (auto j = keys.rbegin(); j != keys.rend(); ++j) {  // :103-117
+    if (!b.has_key(*j)) continue;
+    DVec bj = b(*j);
+    for (auto i = j + 1; i != keys.rend(); ++i)
+      if (LT.has_key(*i, *j)) b.InsertOrAddApply(*i, LT(*i, *j).impl(), bj, -1.0);
+  }
+  return b;
+}
+
+void BlockCholesky::Compute(BlockMatrix A) {  // :119-133
+  const size_t n_cols = A.col_keys().size();
+  for (size_t i = 0; i < n_cols; ++i) {
+    std::string key = NextKey(A);
+    BlockMatrix Di_inv;
+    Di_inv(key, key) = A(key, key).Inverse();
+    BlockMatrix V = RemoveKey(&A, key);
+    L_ = L_ + V * Di_inv;
+    D_inv_ = D_inv_ + Di_inv;
+    A = A - V * Di_inv * V.Transpose();
+    p_.push_back(key);
+  }
+  LT_ = L_.Transpose();
+}
+
+BlockVector BlockCholesky::Solve(const BlockVector& b) const {  // :135-137
+  return BackSub(LT_, p_, D_inv_ * ForwardSub(L_, p_, b));
+}
+
+}  // namespace eps

@@ -1,0 +1,338 @@
+// extern "C" boundary: see include/epsilon_hip.h for the contract of each function and the
+// reference interface it replaces (python/epopt/solvemodule.cc).
+#include "../../include/epsilon_hip.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "admm.h"
+#include "kernels.h"
+#include "linear_map.h"
+#include "wire.h"
+
+using namespace eps;
+
+struct eps_result {
+  std::string status;
+  std::vector<std::string> ids;
+  std::vector<std::vector<double>> values;
+};
+
+struct eps_solver {
+  std::shared_ptr<DataMap> data;
+  std::unique_ptr<Solver> solver;
+  DType dtype;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+int g_dtype_option = -1;  // -1: take EPSILON_HIP_DTYPE / default
+
+DType ConfiguredDType() {
+  if (g_dtype_option >= 0) return static_cast<DType>(g_dtype_option);
+  const char* e = std::getenv("EPSILON_HIP_DTYPE");
+  if (e && (std::strcmp(e, "f64") == 0 || std::strcmp(e, "float64") == 0)) return F64;
+  return F32;
+}
+
+template <class F> int Guard(F f) {
+  try {
+    g_last_error.clear();
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+  } catch (...) {
+    g_last_error = "unknown error";
+  }
+  // leave no half-finished GPU work behind
+  (void)hipGetLastError();
+  return 1;
+}
+
+std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType dt) {
+  auto dm = std::make_shared<DataMap>(dt);
+  for (size_t i = 0; i < ndata; ++i) {
+    EPS_CHECK_MSG(data[i].key != nullptr, "data blob without a key");
+    Blob b;
+    b.ptr = data[i].ptr;
+    b.len = data[i].len;
+    b.kind = data[i].kind;
+    EPS_CHECK_MSG(b.kind >= 0 && b.kind <= 2, "bad blob kind " << b.kind);
+    dm->Insert(data[i].key, b);
+  }
+  return dm;
+}
+
+void FillResult(Solver* solver, eps_result* r) {
+  r->status = solver->status().Serialize();
+  BlockVector x = solver->GetSolution();
+  for (const auto& var : GetVariables(solver->problem())) {  // solvemodule.cc:166-176
+    r->ids.push_back(var.first);
+    r->values.push_back(x(var.first).ToHost());
+  }
+}
+
+void LogToStdout(const std::string& msg) {  // reference util/logging.cc:10-13 -> PySys_WriteStdout
+  std::fputs(msg.c_str(), stdout);
+  std::fputc('\n', stdout);
+  std::fflush(stdout);
+}
+
+LinearMap ParseMap(const void* bytes, size_t len, DataMap* dm) {
+  pb::LinearMap p = pb::ParseLinearMap(bytes, len);
+  return BuildLinearMap(p, dm);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eps_last_error(void) { return g_last_error.c_str(); }
+
+const char* eps_version(void) { return "epsilon_hip 0.1 gfx950"; }
+
+int eps_set_option(const char* key, const char* value) {
+  return Guard([&] {
+    EPS_CHECK(key != nullptr && value != nullptr);
+    if (std::strcmp(key, "dtype") == 0) {
+      if (std::strcmp(value, "f32") == 0) g_dtype_option = F32;
+      else if (std::strcmp(value, "f64") == 0) g_dtype_option = F64;
+      else EPS_FATAL("dtype must be f32 or f64, got " << value);
+    } else if (std::strcmp(key, "device") == 0) {
+      setenv("EPSILON_HIP_DEVICE", value, 1);
+    } else if (std::strcmp(key, "gemm") == 0) {
+      setenv("EPSILON_HIP_GEMM", value, 1);
+    } else {
+      EPS_FATAL("unknown option " << key);
+    }
+  });
+}
+
+int eps_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count;
+}
+
+int eps_solve(const void* problem, size_t problem_len, const void* solver_params,
+              size_t solver_params_len, const eps_blob* data, size_t ndata,
+              const eps_param* params, size_t nparams, eps_result** out) {
+  return Guard([&] {
+    EPS_CHECK(out != nullptr);
+    *out = nullptr;
+    const DType dt = ConfiguredDType();
+    SetCurrentDType(dt);
+    pb::Problem p = pb::ParseProblem(problem, problem_len);
+    pb::SolverParams sp = pb::ParseSolverParams(solver_params, solver_params_len);
+    auto dm = MakeDataMap(data, ndata, dt);
+    for (size_t i = 0; i < nparams; ++i)
+      dm->SetParameter(params[i].id, pb::ParseConstant(params[i].constant_proto, params[i].len));
+    std::unique_ptr<Solver> solver = CreateSolver(std::move(p), dm, sp);
+    solver->set_log(LogToStdout);
+    solver->Solve();
+    std::unique_ptr<eps_result> r(new eps_result);
+    FillResult(solver.get(), r.get());
+    *out = r.release();
+  });
+}
+
+int eps_eval_prox(const void* f_expr, size_t f_expr_len, double lambda, const eps_blob* data,
+                  size_t ndata, const eps_blob* v, size_t nv, eps_result** out) {
+  return Guard([&] {
+    EPS_CHECK(out != nullptr);
+    *out = nullptr;
+    const DType dt = ConfiguredDType();
+    SetCurrentDType(dt);
+    pb::Expression e = pb::ParseExpression(f_expr, f_expr_len);
+    auto dm = MakeDataMap(data, ndata, dt);
+    BlockVector vin;
+    for (size_t i = 0; i < nv; ++i) {
+      EPS_CHECK_MSG(v[i].kind == EPS_BLOB_HOST && v[i].len % sizeof(double) == 0,
+                    "eval_prox: v must be host float64 bytes");
+      vin.Set(v[i].key, DVec::FromHost(static_cast<const double*>(v[i].ptr),
+                                       static_cast<int64_t>(v[i].len / sizeof(double)), dt));
+    }
+    BlockVector x = EvalProx(e, lambda, dm.get(), vin);
+    std::unique_ptr<eps_result> r(new eps_result);
+    for (const auto& kv : x.data()) {  // GetVariableMap, solvemodule.cc:45-56
+      r->ids.push_back(kv.first);
+      r->values.push_back(kv.second.ToHost());
+    }
+    *out = r.release();
+  });
+}
+
+int eps_result_status(const eps_result* r, const void** bytes, size_t* len) {
+  if (!r || !bytes || !len) return 1;
+  *bytes = r->status.data();
+  *len = r->status.size();
+  return 0;
+}
+
+size_t eps_result_num_vars(const eps_result* r) { return r ? r->ids.size() : 0; }
+
+int eps_result_var(const eps_result* r, size_t i, const char** id, const double** values,
+                   size_t* count) {
+  if (!r || i >= r->ids.size()) return 1;
+  if (id) *id = r->ids[i].c_str();
+  if (values) *values = r->values[i].data();
+  if (count) *count = r->values[i].size();
+  return 0;
+}
+
+void eps_result_free(eps_result* r) { delete r; }
+
+int eps_solver_create(const void* problem, size_t problem_len, const void* solver_params,
+                      size_t solver_params_len, const eps_blob* data, size_t ndata,
+                      eps_solver** out) {
+  return Guard([&] {
+    EPS_CHECK(out != nullptr);
+    *out = nullptr;
+    const DType dt = ConfiguredDType();
+    SetCurrentDType(dt);
+    std::unique_ptr<eps_solver> s(new eps_solver);
+    s->dtype = dt;
+    s->data = MakeDataMap(data, ndata, dt);
+    s->solver = CreateSolver(pb::ParseProblem(problem, problem_len), s->data,
+                             pb::ParseSolverParams(solver_params, solver_params_len));
+    s->solver->set_log(LogToStdout);
+    *out = s.release();
+  });
+}
+
+int eps_solver_set_parameter(eps_solver* s, const char* id, const void* constant_proto,
+                             size_t len, const eps_blob* data, size_t ndata) {
+  return Guard([&] {
+    EPS_CHECK(s != nullptr && id != nullptr);
+    for (size_t i = 0; i < ndata; ++i) {
+      Blob b;
+      b.ptr = data[i].ptr;
+      b.len = data[i].len;
+      b.kind = data[i].kind;
+      s->data->Insert(data[i].key, b);
+    }
+    s->data->SetParameter(id, pb::ParseConstant(constant_proto, len));
+  });
+}
+
+int eps_solver_init(eps_solver* s) {
+  return Guard([&] {
+    EPS_CHECK(s != nullptr);
+    SetCurrentDType(s->dtype);
+    s->solver->Init();
+  });
+}
+
+int eps_solver_run(eps_solver* s, int max_sweeps, int* sweeps_done) {
+  return Guard([&] {
+    EPS_CHECK(s != nullptr);
+    SetCurrentDType(s->dtype);
+    int done = s->solver->Run(max_sweeps);
+    if (sweeps_done) *sweeps_done = done;
+  });
+}
+
+int eps_solver_result(eps_solver* s, eps_result** out) {
+  return Guard([&] {
+    EPS_CHECK(s != nullptr && out != nullptr);
+    *out = nullptr;
+    SetCurrentDType(s->dtype);
+    std::unique_ptr<eps_result> r(new eps_result);
+    FillResult(s->solver.get(), r.get());
+    *out = r.release();
+  });
+}
+
+int eps_solver_timing(const eps_solver* s, double* init_seconds, double* loop_seconds) {
+  if (!s) return 1;
+  if (init_seconds) *init_seconds = s->solver->init_seconds();
+  if (loop_seconds) *loop_seconds = s->solver->loop_seconds();
+  return 0;
+}
+
+void eps_solver_destroy(eps_solver* s) {
+  try {
+    delete s;
+  } catch (...) {
+  }
+}
+
+int eps_linear_map_apply(const void* linear_map, size_t len, const eps_blob* data, size_t ndata,
+                         int transpose, const double* x, size_t nx, double* y, size_t ny) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    SetCurrentDType(dt);
+    auto dm = MakeDataMap(data, ndata, dt);
+    LinearMap A = ParseMap(linear_map, len, dm.get());
+    if (transpose) A = A.Transpose();
+    EPS_CHECK_MSG(static_cast<int64_t>(nx) == A.impl().n() && static_cast<int64_t>(ny) == A.impl().m(),
+                  "map is " << A.impl().m() << " x " << A.impl().n() << ", got x of " << nx
+                            << " and y of " << ny);
+    DVec xd = DVec::FromHost(x, nx, dt);
+    DVec yd = DVec::Empty(ny, dt);
+    A.impl().Apply(1.0, xd, 0.0, yd);
+    yd.ToHost(y);
+  });
+}
+
+int eps_linear_map_binary(char op, const void* a, size_t a_len, int ta, const void* b,
+                          size_t b_len, int tb, const eps_blob* data, size_t ndata,
+                          int* result_type, int64_t* m, int64_t* n, double* dense,
+                          size_t dense_capacity) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    SetCurrentDType(dt);
+    auto dm = MakeDataMap(data, ndata, dt);
+    LinearMap A = ParseMap(a, a_len, dm.get());
+    LinearMap B = ParseMap(b, b_len, dm.get());
+    if (ta) A = A.Transpose();
+    if (tb) B = B.Transpose();
+    LinearMap C;
+    if (op == '+') C = A + B;
+    else if (op == '*') C = A * B;
+    else EPS_FATAL("op must be '+' or '*'");
+    if (result_type) *result_type = static_cast<int>(C.impl().type());
+    if (m) *m = C.impl().m();
+    if (n) *n = C.impl().n();
+    if (dense) {
+      std::vector<double> D = C.impl().AsDenseHost();
+      EPS_CHECK_MSG(D.size() <= dense_capacity, "dense output buffer too small");
+      std::memcpy(dense, D.data(), D.size() * sizeof(double));
+    }
+  });
+}
+
+int eps_linear_map_inverse(const void* linear_map, size_t len, const eps_blob* data,
+                           size_t ndata, double* dense, size_t dense_capacity) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    SetCurrentDType(dt);
+    auto dm = MakeDataMap(data, ndata, dt);
+    LinearMap A = ParseMap(linear_map, len, dm.get()).Inverse();
+    std::vector<double> D = A.impl().AsDenseHost();
+    EPS_CHECK_MSG(D.size() <= dense_capacity, "dense output buffer too small");
+    std::memcpy(dense, D.data(), D.size() * sizeof(double));
+  });
+}
+
+int eps_tv1d(const double* v, size_t n, double lam, double* x) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    DVec vd = DVec::FromHost(v, n, dt);
+    DVec xd = DVec::Empty(n, dt);
+    k::Tv1d(xd, vd, lam);
+    xd.ToHost(x);
+  });
+}
+
+}  // extern "C"

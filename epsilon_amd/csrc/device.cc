@@ -1,0 +1,211 @@
+#include "device.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace eps {
+
+Buffer::~Buffer() {
+  if (owned && p) Runtime::Get().Release(p, bytes);
+}
+
+Runtime& Runtime::Get() {
+  static Runtime* rt = new Runtime();  // leaked on purpose: outlives static destructors
+  return *rt;
+}
+
+Runtime::Runtime() {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    EPS_FATAL("no HIP device available: the epsilon_hip solver has no CPU fallback ("
+              << hipGetErrorString(e) << ")");
+  }
+  const char* env = std::getenv("EPSILON_HIP_DEVICE");
+  if (env == nullptr) env = std::getenv("LOCAL_RANK");
+  device_ = env ? std::atoi(env) % count : 0;
+  EPS_HIP(hipSetDevice(device_));
+  EPS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  EPS_HIP(hipMalloc(reinterpret_cast<void**>(&slots_dev_), kMaxSlots * sizeof(double)));
+  EPS_HIP(hipHostMalloc(reinterpret_cast<void**>(&slots_host_), kMaxSlots * sizeof(double),
+                        hipHostMallocDefault));
+  EPS_HIP(hipMemsetAsync(slots_dev_, 0, kMaxSlots * sizeof(double), stream_));
+}
+
+Runtime::~Runtime() {}
+
+static size_t RoundUp(size_t bytes) {
+  const size_t g = 256;
+  return bytes == 0 ? g : (bytes + g - 1) / g * g;
+}
+
+std::shared_ptr<Buffer> Runtime::Alloc(size_t bytes) {
+  bytes = RoundUp(bytes);
+  auto b = std::make_shared<Buffer>();
+  b->bytes = bytes;
+  auto it = pool_.find(bytes);
+  if (it != pool_.end()) {
+    b->p = it->second;
+    pool_.erase(it);
+    pooled_ -= bytes;
+  } else {
+    EPS_HIP(hipSetDevice(device_));
+    hipError_t e = hipMalloc(&b->p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      TrimPool();
+      EPS_HIP(hipMalloc(&b->p, bytes));
+    }
+  }
+  in_use_ += bytes;
+  return b;
+}
+
+void Runtime::Release(void* p, size_t bytes) {
+  // Single-stream ordering makes immediate reuse safe: any kernel that touched `p` was
+  // enqueued before whatever the next owner enqueues.
+  pool_.emplace(bytes, p);
+  in_use_ -= bytes;
+  pooled_ += bytes;
+}
+
+void Runtime::TrimPool() {
+  EPS_HIP(hipStreamSynchronize(stream_));
+  for (auto& kv : pool_) (void)hipFree(kv.second);
+  pool_.clear();
+  pooled_ = 0;
+}
+
+void* Runtime::Scratch(size_t bytes) {
+  if (bytes > scratch_bytes_) {
+    if (scratch_) {
+      EPS_HIP(hipStreamSynchronize(stream_));
+      EPS_HIP(hipFree(scratch_));
+    }
+    scratch_bytes_ = RoundUp(bytes < (1u << 20) ? (1u << 20) : bytes);
+    EPS_HIP(hipMalloc(&scratch_, scratch_bytes_));
+  }
+  return scratch_;
+}
+
+int Runtime::NewSlot() {
+  EPS_CHECK_MSG(slots_used_ < kMaxSlots, "out of reduction slots");
+  return slots_used_++;
+}
+
+void Runtime::FetchSlots() {
+  if (slots_used_ > 0) {
+    EPS_HIP(hipMemcpyAsync(slots_host_, slots_dev_, slots_used_ * sizeof(double),
+                           hipMemcpyDeviceToHost, stream_));
+  }
+  EPS_HIP(hipStreamSynchronize(stream_));
+}
+
+void Runtime::Sync() { EPS_HIP(hipStreamSynchronize(stream_)); }
+
+static thread_local DType g_current_dtype = F32;
+DType CurrentDType() { return g_current_dtype; }
+void SetCurrentDType(DType dt) { g_current_dtype = dt; }
+
+// ---- DVec -------------------------------------------------------------------------------------
+
+DVec DVec::Empty(int64_t n, DType dt) {
+  EPS_CHECK(n >= 0);
+  DVec v;
+  v.n = n;
+  v.dt = dt;
+  v.buf = Runtime::Get().Alloc(static_cast<size_t>(n) * DTypeSize(dt));
+  return v;
+}
+
+DVec DVec::Zeros(int64_t n, DType dt) {
+  DVec v = Empty(n, dt);
+  if (n > 0) EPS_HIP(hipMemsetAsync(v.data(), 0, v.bytes(), Runtime::Get().stream()));
+  return v;
+}
+
+DVec DVec::Full(int64_t n, double val, DType dt) {
+  DVec v = Empty(n, dt);
+  k::Fill(v, val);
+  return v;
+}
+
+DVec DVec::FromHost(const double* src, int64_t n, DType dt) {
+  DVec v = Empty(n, dt);
+  if (n == 0) return v;
+  Runtime& rt = Runtime::Get();
+  if (dt == F64) {
+    EPS_HIP(hipMemcpyAsync(v.data(), src, n * sizeof(double), hipMemcpyHostToDevice,
+                           rt.stream()));
+    // pageable host memory: the copy is staged, the source may be reused after return only
+    // once the stream has consumed it
+    EPS_HIP(hipStreamSynchronize(rt.stream()));
+  } else {
+    // stage in chunks of <= 256 MiB of doubles, convert on the device
+    const int64_t chunk = int64_t(1) << 25;
+    auto stage = rt.Alloc(static_cast<size_t>(std::min(n, chunk)) * sizeof(double));
+    for (int64_t off = 0; off < n; off += chunk) {
+      int64_t len = std::min(chunk, n - off);
+      EPS_HIP(hipMemcpyAsync(stage->p, src + off, len * sizeof(double),
+                             hipMemcpyHostToDevice, rt.stream()));
+      k::ConvertFromF64(v.Slice(off, len), static_cast<const double*>(stage->p));
+      EPS_HIP(hipStreamSynchronize(rt.stream()));
+    }
+  }
+  return v;
+}
+
+DVec DVec::Borrow(void* dev_ptr, int64_t n, DType dt) {
+  DVec v;
+  v.n = n;
+  v.dt = dt;
+  v.buf = std::make_shared<Buffer>();
+  v.buf->p = dev_ptr;
+  v.buf->bytes = static_cast<size_t>(n) * DTypeSize(dt);
+  v.buf->owned = false;
+  return v;
+}
+
+DVec DVec::Slice(int64_t start, int64_t len) const {
+  EPS_CHECK(start >= 0 && len >= 0 && start + len <= n);
+  DVec v = *this;
+  v.offset = offset + static_cast<size_t>(start) * DTypeSize(dt);
+  v.n = len;
+  return v;
+}
+
+DVec DVec::Clone() const {
+  DVec v = Empty(n, dt);
+  if (n > 0) k::Copy(v, *this);
+  return v;
+}
+
+void DVec::ToHost(double* dst) const {
+  if (n == 0) return;
+  Runtime& rt = Runtime::Get();
+  if (dt == F64) {
+    EPS_HIP(hipMemcpyAsync(dst, data(), n * sizeof(double), hipMemcpyDeviceToHost,
+                           rt.stream()));
+    EPS_HIP(hipStreamSynchronize(rt.stream()));
+    return;
+  }
+  const int64_t chunk = int64_t(1) << 25;
+  auto stage = rt.Alloc(static_cast<size_t>(std::min(n, chunk)) * sizeof(double));
+  for (int64_t off = 0; off < n; off += chunk) {
+    int64_t len = std::min(chunk, n - off);
+    k::ConvertToF64(static_cast<double*>(stage->p), Slice(off, len));
+    EPS_HIP(hipMemcpyAsync(dst + off, stage->p, len * sizeof(double), hipMemcpyDeviceToHost,
+                           rt.stream()));
+    EPS_HIP(hipStreamSynchronize(rt.stream()));
+  }
+}
+
+std::vector<double> DVec::ToHost() const {
+  std::vector<double> out(n);
+  ToHost(out.data());
+  return out;
+}
+
+}  // namespace eps

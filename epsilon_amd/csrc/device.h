@@ -1,0 +1,110 @@
+// Device runtime: one HIP stream, a size-binned buffer pool, device scalar slots for
+// deferred reductions, and DVec (a typed view of pooled HBM).
+//
+// The reference keeps every vector as an Eigen::VectorXd and allocates on each BlockVector
+// operation (reference src/epsilon/vector/block_vector.cc:9-48).  Here all iterate state
+// lives in HBM; temporaries come from a pool so that after the first sweep no hipMalloc
+// happens, and norms are reduced into device-side "slots" that are read back with one
+// copy per residual check instead of one sync per norm.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace eps {
+
+class Runtime;
+
+struct Buffer {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool owned = true;  // false: borrowed device pointer (caller-resident blob)
+  ~Buffer();
+};
+
+class Comm;  // collective backend (comm.h)
+
+class Runtime {
+ public:
+  static Runtime& Get();
+
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+
+  std::shared_ptr<Buffer> Alloc(size_t bytes);
+  void Release(void* p, size_t bytes);
+  void TrimPool();
+  size_t bytes_in_use() const { return in_use_; }
+  size_t bytes_pooled() const { return pooled_; }
+
+  // Reduction scratch (per-workgroup partials), at least `bytes` large.
+  void* Scratch(size_t bytes);
+
+  // Device scalar slots (doubles).  ResetSlots() rewinds the allocator; FetchSlots()
+  // copies all used slots to the host with ONE async copy + stream sync.
+  int NewSlot();
+  double* SlotPtr(int i) { return slots_dev_ + i; }
+  void ResetSlots() { slots_used_ = 0; }
+  void FetchSlots();
+  double SlotValue(int i) const { return slots_host_[i]; }
+
+  void Sync();
+
+  Comm* comm() { return comm_; }
+  void set_comm(Comm* c) { comm_ = c; }
+
+  static constexpr int kMaxSlots = 4096;
+
+ private:
+  Runtime();
+  ~Runtime();
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  std::multimap<size_t, void*> pool_;
+  size_t in_use_ = 0, pooled_ = 0;
+  void* scratch_ = nullptr;
+  size_t scratch_bytes_ = 0;
+  double* slots_dev_ = nullptr;
+  double* slots_host_ = nullptr;
+  int slots_used_ = 0;
+  Comm* comm_ = nullptr;
+};
+
+// Compute dtype of the solve being set up on this thread (f32 unless EPSILON_HIP_DTYPE=f64 or
+// eps_set_option("dtype", ...)); maps without data of their own (scalars) take it from here.
+DType CurrentDType();
+void SetCurrentDType(DType dt);
+
+// Typed device vector view.  Copying a DVec shares the buffer (like shared_ptr).
+struct DVec {
+  std::shared_ptr<Buffer> buf;
+  size_t offset = 0;  // bytes
+  int64_t n = 0;
+  DType dt = F32;
+
+  bool defined() const { return buf != nullptr || n == 0; }
+  void* data() const { return buf ? static_cast<char*>(buf->p) + offset : nullptr; }
+  template <class T> T* as() const { return static_cast<T*>(data()); }
+  size_t bytes() const { return static_cast<size_t>(n) * DTypeSize(dt); }
+
+  static DVec Empty(int64_t n, DType dt);
+  static DVec Zeros(int64_t n, DType dt);
+  static DVec Full(int64_t n, double v, DType dt);
+  // Host double -> device dt (converted on the device).
+  static DVec FromHost(const double* src, int64_t n, DType dt);
+  // Borrowed device memory (no copy, not freed).
+  static DVec Borrow(void* dev_ptr, int64_t n, DType dt);
+  DVec Slice(int64_t start, int64_t len) const;
+  DVec Clone() const;
+  std::vector<double> ToHost() const;  // synchronises
+  void ToHost(double* dst) const;
+};
+
+}  // namespace eps

@@ -1,0 +1,83 @@
+// Launchers for the hand-written gfx950 kernels.  All launch on Runtime::Get().stream().
+// DVec arguments carry their dtype (f32 / f64); scalars are passed as double and narrowed in
+// the kernel.  Reference call sites replaced are cited per group.
+#pragma once
+
+#include "device.h"
+
+namespace eps {
+namespace k {
+
+// ---- K7: BlockVector += -= *=, scalar / diagonal Apply -------------------------------------
+// (reference vector/block_vector.cc:9-48, linear/scalar_matrix_impl.h:24,
+//  linear/diagonal_matrix_impl.h:23)
+void Fill(const DVec& y, double v);
+void Copy(const DVec& dst, const DVec& src);
+// y = a*x + b*y   (b == 0 never reads y)
+void Axpby(const DVec& y, double a, const DVec& x, double b);
+// y = a * d .* x + b*y
+void DiagMul(const DVec& y, double a, const DVec& d, const DVec& x, double b);
+// host f64 staging buffer (device memory, doubles) -> dst (dst.dt)
+void ConvertFromF64(const DVec& dst, const double* src_dev);
+// src (any dt) -> device doubles
+void ConvertToF64(double* dst_dev, const DVec& src);
+void ConvertFromF32(const DVec& dst, const float* src_dev);
+
+// ---- K8: norms (reference vector/block_vector.cc:87-93) -----------------------------------
+// *slot = (accumulate ? *slot : 0) + sum_i x_i^2, accumulated in double, deterministic.
+void SumSq(const DVec& x, double* slot, bool accumulate);
+// *slot (+)= sum_i (x_i - y_i)^2
+void SumSqDiff(const DVec& x, const DVec& y, double* slot, bool accumulate);
+void Dot(const DVec& x, const DVec& y, double* slot, bool accumulate);
+
+// ---- K1/K2/K3: dense mat-vec (reference linear/dense_matrix_impl.cc:55-67 dgemv_) --------
+// y = alpha * op(A) x + beta*y ; A is rows x cols column-major with leading dimension lda.
+void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, int64_t lda,
+          const DVec& x, double beta, const DVec& y);
+
+// ---- K4: dense mat-mat (reference linear/linear_map_multiply.cc:14-37 dgemm_) -------------
+// C (M x N, ldc) = alpha * op(A) (M x K) * op(B) (K x N) + beta * C ; column-major.
+// lower_only: compute only tiles touching the lower triangle (SYRK-style); the caller
+// mirrors with SymmetrizeFromLower.
+void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+          const DVec& A, int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C,
+          int64_t ldc, bool lower_only = false);
+void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc);
+
+// dst (rows x cols, ld = rows) = alpha * op(src)
+void MatCopy(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& src,
+             int64_t lds, const DVec& dst);
+// W[i,i] += alpha (d undefined) or W[i,i] += alpha*d[i]
+void AddDiag(const DVec& W, int64_t n, int64_t ld, double alpha, const DVec* d);
+// dst (mA*mB x nA*nB) = kron(A, B), all column-major contiguous
+void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVec& B,
+               int64_t mB, int64_t nB);
+// y = A x for W = diag? helpers used by Kronecker apply are composed from Gemm.
+
+// ---- K5: symmetric definite inverse (reference linear/dense_matrix_impl.cc:21-30) ---------
+// W (n x n, ld = n, symmetric positive definite, full storage) -> W^{-1} in place.
+// Blocked Cholesky + triangular inverse + X^T X, all on device.  Throws if a pivot is <= 0.
+void SpdInverseInPlace(const DVec& W, int64_t n);
+
+// ---- K6 / K12: elementwise and group prox kernels ------------------------------------------
+// reference prox/scaled_zone.cc:78-104 ; lam / alpha / beta are either uniform scalars or
+// per-element device vectors (pass defined DVecs to use the vector form).
+struct ScaledZoneArgs {
+  double lam = 0, alpha = 1, beta = 1, M = 0, C = 0;
+  const DVec* lam_vec = nullptr;
+  const DVec* alpha_vec = nullptr;
+  const DVec* beta_vec = nullptr;
+  int64_t period = 0;  // >0: alpha/beta/lam vectors are indexed by (i % period)
+};
+void ScaledZone(const DVec& x, const DVec& v, const ScaledZoneArgs& args);
+// reference prox/non_negative.cc:8
+void MaxZero(const DVec& x, const DVec& v);
+// reference prox/norm_2.cc:11-16 ; normsq is a device slot holding ||v||^2
+void Norm2Shrink(const DVec& x, const DVec& v, double lam, const double* normsq);
+// x = soft-threshold of singular values etc. is composed from ScaledZone.
+
+// reference prox/total_variation_1d.cc:21 (glmgen tf_dp): exact 1-D TV prox
+void Tv1d(const DVec& x, const DVec& v, double lam);
+
+}  // namespace k
+}  // namespace eps

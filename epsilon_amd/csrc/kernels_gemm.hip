@@ -1,0 +1,258 @@
+// K4: dense matrix-matrix products (the Gram contraction A A^T / A^T A of the least-squares
+// prox, the blocked Cholesky updates, Kronecker applies).
+//
+// The reference calls `dgemm_` (reference src/epsilon/linear/linear_map_multiply.cc:14-37).
+// Two kernels:
+//
+//  * GemmMfmaF32: 128x128 output tile per 256-thread workgroup (4 wavefronts as 2x2, each
+//    wavefront 2x2 tiles of v_mfma_f32_32x32x2_f32), BK = 32 slabs staged through LDS as
+//    [k][row] so one ds_read_b32 per lane feeds an MFMA operand directly.  f32 in / f32
+//    accumulate MFMA is bit-for-bit an fmaf chain on gfx950 (no TF32), so this is exact fp32.
+//    The accumulator is produced transposed (MFMA "A" operand <- B tile) so that a register's
+//    32 lanes hit 32 consecutive rows of column-major C: 128-byte coalesced stores.
+//  * GemmGeneric<T>: 64x64 LDS-tiled VALU kernel for f64 and for small shapes.
+//
+// `lower_only` skips tiles strictly above the diagonal (SYRK-style, half the flops).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// element (r, c) of op(X) where X is column-major with leading dimension ld
+template <class T>
+__device__ inline T OpAt(const T* X, int64_t ld, bool trans, int64_t r, int64_t c) {
+  return trans ? X[c + r * ld] : X[r + c * ld];
+}
+
+// ------------------------------------------------------------------------------------------
+// generic tiled kernel
+// ------------------------------------------------------------------------------------------
+constexpr int GT = 64;   // tile
+constexpr int GK = 16;   // k slab
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void GemmGenericKernel(
+    int transA, int transB, int64_t M, int64_t N, int64_t K, T alpha, const T* __restrict__ A,
+    int64_t lda, const T* __restrict__ B, int64_t ldb, T beta, T* C, int64_t ldc,
+    int lower_only) {
+  __shared__ T As[GK][GT + 1];
+  __shared__ T Bs[GK][GT + 1];
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * GT;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * GT;
+  if (lower_only && i0 + GT <= j0) return;  // tile entirely above the diagonal
+  const int t = threadIdx.x;
+  const int tx = t & 15, ty = t >> 4;
+  T acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = T(0);
+
+  for (int64_t k0 = 0; k0 < K; k0 += GK) {
+    // stage op(A)[i0:i0+64, k0:k0+16] as As[k][i], op(B)[k0:k0+16, j0:j0+64] as Bs[k][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int ii, kk;
+      if (!transA) { ii = t & 63; kk = (t >> 6) + 4 * r; }   // contiguous along i
+      else { kk = t & 15; ii = (t >> 4) + 16 * r; }          // contiguous along k
+      const int64_t gi = i0 + ii, gk = k0 + kk;
+      As[kk][ii] = (gi < M && gk < K) ? OpAt(A, lda, transA != 0, gi, gk) : T(0);
+      int jj, kb;
+      if (transB) { jj = t & 63; kb = (t >> 6) + 4 * r; }    // op(B)(k,j) = B[j + k*ldb]
+      else { kb = t & 15; jj = (t >> 4) + 16 * r; }          // op(B)(k,j) = B[k + j*ldb]
+      const int64_t gj = j0 + jj, gkb = k0 + kb;
+      Bs[kb][jj] = (gj < N && gkb < K) ? OpAt(B, ldb, transB != 0, gkb, gj) : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; ++kk) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = As[kk][tx + 16 * a];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = Bs[kk][ty + 16 * b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int64_t j = j0 + ty + 16 * b;
+    if (j >= N) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t i = i0 + tx + 16 * a;
+      if (i >= M) continue;
+      T* c = C + i + j * ldc;
+      *c = (beta == T(0)) ? alpha * acc[a][b] : alpha * acc[a][b] + beta * (*c);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 MFMA kernel
+// ------------------------------------------------------------------------------------------
+constexpr int MT = 128;        // output tile (rows and cols)
+constexpr int MK = 32;         // k slab
+constexpr int MLD = MT + 1;    // LDS row stride (floats): conflict-free for both loaders
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Stage op(X)[r0 : r0+128, k0 : k0+32] (r = the non-contracted index) into S[k][r].
+//   contiguous_r == true : memory is contiguous along r   (X[r + k*ld])
+//   contiguous_r == false: memory is contiguous along k   (X[k + r*ld])
+__device__ inline void StageTile(float (*S)[MLD], const float* __restrict__ X, int64_t ld,
+                                 bool contiguous_r, int64_t r0, int64_t k0, int64_t R,
+                                 int64_t K) {
+  const int t = threadIdx.x;
+  if (contiguous_r) {
+    const int rr = t & 127;
+    const int kb = t >> 7;  // 0..1
+    const int64_t gr = r0 + rr;
+#pragma unroll
+    for (int p = 0; p < MK / 2; ++p) {
+      const int kk = kb + 2 * p;
+      const int64_t gk = k0 + kk;
+      S[kk][rr] = (gr < R && gk < K) ? X[gr + gk * ld] : 0.0f;
+    }
+  } else {
+    const int kk = t & 31;
+    const int rb = t >> 5;  // 0..7
+    const int64_t gk = k0 + kk;
+#pragma unroll
+    for (int p = 0; p < MT / 8; ++p) {
+      const int rr = rb + 8 * p;
+      const int64_t gr = r0 + rr;
+      S[kk][rr] = (gr < R && gk < K) ? X[gk + gr * ld] : 0.0f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void GemmMfmaF32Kernel(
+    int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+    float beta, float* C, int64_t ldc, int lower_only) {
+  __shared__ float As[MK][MLD];
+  __shared__ float Bs[MK][MLD];
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * MT;
+  if (lower_only && i0 + MT <= j0) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave & 1, wj = wave >> 1;  // wavefront's 64x64 quadrant
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  for (int64_t k0 = 0; k0 < K; k0 += MK) {
+    // op(A)(i,k): contiguous along i when A is not transposed; op(B)(k,j): contiguous along j
+    // when B IS transposed (B stored N x K).
+    StageTile(As, A, lda, transA == 0, i0, k0, M, K);
+    StageTile(Bs, B, ldb, transB != 0, j0, k0, N, K);
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < MK; kk += 2) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = As[kk + lh][wi * 64 + a * 32 + l31];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = Bs[kk + lh][wj * 64 + b * 32 + l31];
+      // D'[j][i] += Bop[k][j] * Aop[i][k]: MFMA "A" operand = B values, "B" operand = A values
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[b], av[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // acc[a][b][reg]: j_local = (reg&3) + 8*(reg>>2) + 4*lh , i_local = l31
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int64_t i = i0 + wi * 64 + a * 32 + l31;
+    if (i >= M) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (j >= N) continue;
+        float* c = C + i + j * ldc;
+        const float v = alpha * acc[a][b][r];
+        *c = (beta == 0.0f) ? v : v + beta * (*c);
+      }
+    }
+  }
+}
+
+int GemmMode() {  // 0 auto, 1 generic, 2 mfma
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = std::getenv("EPSILON_HIP_GEMM");
+    mode = 0;
+    if (e && std::strcmp(e, "generic") == 0) mode = 1;
+    if (e && std::strcmp(e, "mfma") == 0) mode = 2;
+  }
+  return mode;
+}
+
+}  // namespace
+
+void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+          const DVec& A, int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C,
+          int64_t ldc, bool lower_only) {
+  EPS_CHECK(A.dt == B.dt && A.dt == C.dt);
+  if (M == 0 || N == 0) return;
+  const int64_t a_rows = transA ? K : M, a_cols = transA ? M : K;
+  const int64_t b_rows = transB ? N : K, b_cols = transB ? K : N;
+  EPS_CHECK_MSG(lda >= a_rows && ldb >= b_rows && ldc >= M, "gemm: bad leading dimension");
+  EPS_CHECK_MSG(K == 0 || A.n >= (a_cols - 1) * lda + a_rows, "gemm: A buffer too small");
+  EPS_CHECK_MSG(K == 0 || B.n >= (b_cols - 1) * ldb + b_rows, "gemm: B buffer too small");
+  EPS_CHECK_MSG(C.n >= (N - 1) * ldc + M, "gemm: C buffer too small");
+  if (lower_only) EPS_CHECK(M == N);
+  hipStream_t s = Runtime::Get().stream();
+  const int mode = GemmMode();
+  const bool use_mfma = A.dt == F32 && mode != 1 &&
+                        (mode == 2 || (M >= 64 && N >= 64 && K >= 32));
+  if (use_mfma) {
+    dim3 grid(static_cast<unsigned>((M + MT - 1) / MT), static_cast<unsigned>((N + MT - 1) / MT));
+    hipLaunchKernelGGL(GemmMfmaF32Kernel, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
+                       transB ? 1 : 0, M, N, K, static_cast<float>(alpha), A.as<float>(), lda,
+                       B.as<float>(), ldb, static_cast<float>(beta), C.as<float>(), ldc,
+                       lower_only ? 1 : 0);
+    return;
+  }
+  dim3 grid(static_cast<unsigned>((M + GT - 1) / GT), static_cast<unsigned>((N + GT - 1) / GT));
+  if (A.dt == F32) {
+    hipLaunchKernelGGL(GemmGenericKernel<float>, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
+                       transB ? 1 : 0, M, N, K, static_cast<float>(alpha), A.as<float>(), lda,
+                       B.as<float>(), ldb, static_cast<float>(beta), C.as<float>(), ldc,
+                       lower_only ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(GemmGenericKernel<double>, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
+                       transB ? 1 : 0, M, N, K, alpha, A.as<double>(), lda, B.as<double>(), ldb,
+                       beta, C.as<double>(), ldc, lower_only ? 1 : 0);
+  }
+}
+
+}  // namespace k
+}  // namespace eps

@@ -1,0 +1,286 @@
+// K1 / K2 / K3: dense matrix-vector products on a column-major matrix, HBM-bound.
+//
+// The reference does both through one `dgemv_` with a trans flag on a shared buffer
+// (reference src/epsilon/linear/dense_matrix_impl.cc:55-67, dense_matrix_impl.h:41-43).
+// Here the two directions are separate kernels because their parallel structure differs:
+//
+//  GemvN  y = alpha*A x + beta*y : a thread owns 4 (f32) / 2 (f64) consecutive rows and walks
+//         a slab of columns; every load is 16 B per lane, fully coalesced down a column.
+//         x for the slab sits in LDS and is read as a broadcast.  The column range is split
+//         over blockIdx.y so the grid fills 256 CUs; the per-slab partial vectors are summed
+//         in a fixed order by a second tiny kernel (deterministic, no float atomics).
+//
+//  GemvT  y = alpha*A^T x + beta*y : a wavefront (64 lanes) owns 4 columns at a time; lanes
+//         stride down the column 16 B each, x comes from LDS (staged once per workgroup when
+//         it fits), the 4 dot products are finished with wave shuffles.  No partials needed.
+//
+// Algorithmic bytes: rows*cols*sizeof(T) per call (A read exactly once); vectors are noise.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <class T> struct VT;
+template <> struct VT<float> {
+  using type = float4;
+  static constexpr int V = 4;
+};
+template <> struct VT<double> {
+  using type = double2;
+  static constexpr int V = 2;
+};
+
+template <class T, int V> struct Ld {
+  __device__ static inline void load(T (&r)[V], const T* p) {
+    using P = typename VT<T>::type;
+    *reinterpret_cast<P*>(r) = *reinterpret_cast<const P*>(p);
+  }
+};
+template <class T> struct Ld<T, 1> {
+  __device__ static inline void load(T (&r)[1], const T* p) { r[0] = *p; }
+};
+
+// ------------------------------------------------------------------------------------------
+// GemvN
+// ------------------------------------------------------------------------------------------
+constexpr int kNChunk = 512;  // columns of x staged in LDS at a time
+constexpr int kNUnroll = 8;   // column loads in flight per thread
+
+template <class T, int V>
+__global__ __launch_bounds__(kBlock) void GemvNKernel(int64_t rows, int64_t cols,
+                                                      const T* __restrict__ A, int64_t lda,
+                                                      const T* __restrict__ x, T alpha, T beta,
+                                                      T* y, T* partial, int64_t cols_per_split) {
+  __shared__ T xs[kNChunk];
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * V;
+  const int64_t c_begin = static_cast<int64_t>(blockIdx.y) * cols_per_split;
+  int64_t c_end = c_begin + cols_per_split;
+  if (c_end > cols) c_end = cols;
+  const bool active = row0 < rows;  // V | rows is guaranteed by the launcher when V > 1
+
+  T acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = T(0);
+
+  for (int64_t c0 = c_begin; c0 < c_end; c0 += kNChunk) {
+    const int nchunk = static_cast<int>((c_end - c0 < kNChunk) ? (c_end - c0) : kNChunk);
+    __syncthreads();
+    for (int j = threadIdx.x; j < nchunk; j += kBlock) xs[j] = x[c0 + j];
+    __syncthreads();
+    if (active) {
+      const T* Ap = A + row0 + c0 * lda;
+      int j = 0;
+      for (; j + kNUnroll <= nchunk; j += kNUnroll) {
+        T a[kNUnroll][V];
+#pragma unroll
+        for (int u = 0; u < kNUnroll; ++u) Ld<T, V>::load(a[u], Ap + (j + u) * lda);
+#pragma unroll
+        for (int u = 0; u < kNUnroll; ++u) {
+          const T xv = xs[j + u];
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[v] += a[u][v] * xv;
+        }
+      }
+      for (; j < nchunk; ++j) {
+        T a[V];
+        Ld<T, V>::load(a, Ap + j * lda);
+        const T xv = xs[j];
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[v] += a[v] * xv;
+      }
+    }
+  }
+  if (!active) return;
+  if (gridDim.y == 1) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int64_t r = row0 + v;
+      y[r] = (beta == T(0)) ? alpha * acc[v] : alpha * acc[v] + beta * y[r];
+    }
+  } else {
+    T* p = partial + static_cast<int64_t>(blockIdx.y) * rows + row0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) p[v] = acc[v];
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void GemvNReduceKernel(int64_t rows, int nsplit,
+                                                            const T* __restrict__ partial,
+                                                            T alpha, T beta, T* y) {
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  T s = T(0);
+  for (int k = 0; k < nsplit; ++k) s += partial[static_cast<int64_t>(k) * rows + r];
+  y[r] = (beta == T(0)) ? alpha * s : alpha * s + beta * y[r];
+}
+
+template <class T>
+void LaunchGemvN(int64_t rows, int64_t cols, double alpha, const T* A, int64_t lda, const T* x,
+                 double beta, T* y) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  constexpr int VV = VT<T>::V;
+  const bool vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % VV == 0) &&
+                   (rows % VV == 0);
+  const int V = vec ? VV : 1;
+  const int64_t row_blocks = (rows + static_cast<int64_t>(kBlock) * V - 1) / (kBlock * V);
+  // split columns so that the grid has >= ~1024 workgroups, slabs of >= 64 columns
+  int64_t nsplit = (1024 + row_blocks - 1) / row_blocks;
+  int64_t max_split = (cols + 63) / 64;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  int64_t cps = (cols + nsplit - 1) / nsplit;
+  nsplit = (cols + cps - 1) / cps;
+  std::shared_ptr<Buffer> part;
+  T* partial = nullptr;
+  if (nsplit > 1) {
+    part = rt.Alloc(static_cast<size_t>(nsplit) * rows * sizeof(T));
+    partial = static_cast<T*>(part->p);
+  }
+  dim3 grid(static_cast<unsigned>(row_blocks), static_cast<unsigned>(nsplit));
+  if (vec) {
+    hipLaunchKernelGGL((GemvNKernel<T, VV>), grid, dim3(kBlock), 0, s, rows, cols, A, lda, x,
+                       T(alpha), T(beta), y, partial, cps);
+  } else {
+    hipLaunchKernelGGL((GemvNKernel<T, 1>), grid, dim3(kBlock), 0, s, rows, cols, A, lda, x,
+                       T(alpha), T(beta), y, partial, cps);
+  }
+  if (nsplit > 1) {
+    hipLaunchKernelGGL(GemvNReduceKernel<T>, dim3(static_cast<unsigned>((rows + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, rows, static_cast<int>(nsplit), partial, T(alpha),
+                       T(beta), y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GemvT
+// ------------------------------------------------------------------------------------------
+constexpr int kTCols = 4;                 // columns per wave per pass
+constexpr int kTLdsBytes = 48 * 1024;     // x staging per workgroup
+
+template <class T> __device__ inline T WaveSumT(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <class T, int V>
+__global__ __launch_bounds__(kBlock) void GemvTKernel(int64_t rows, int64_t cols,
+                                                      const T* __restrict__ A, int64_t lda,
+                                                      const T* __restrict__ x, T alpha, T beta,
+                                                      T* y) {
+  constexpr int RC = kTLdsBytes / sizeof(T);  // rows of x held in LDS
+  __shared__ __attribute__((aligned(16))) T xs[RC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int kWaves = kBlock / 64;
+  const int64_t cols_per_pass = kWaves * kTCols;
+  const int64_t npass = (cols + cols_per_pass - 1) / cols_per_pass;
+  const bool single_chunk = rows <= RC;
+
+  if (single_chunk) {
+    for (int64_t i = threadIdx.x; i < rows; i += kBlock) xs[i] = x[i];
+    __syncthreads();
+  }
+
+  for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    const int64_t j0 = pass * cols_per_pass + wave * kTCols;
+    T acc[kTCols];
+#pragma unroll
+    for (int c = 0; c < kTCols; ++c) acc[c] = T(0);
+
+    for (int64_t r0 = 0; r0 < rows; r0 += RC) {
+      const int64_t nr = (rows - r0 < RC) ? (rows - r0) : RC;
+      if (!single_chunk) {
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < nr; i += kBlock) xs[i] = x[r0 + i];
+        __syncthreads();
+      }
+      if (j0 < cols) {
+        const T* Ap = A + r0 + j0 * lda;
+        const int64_t nvec = (V > 1) ? (nr / V) : 0;
+#pragma unroll 2
+        for (int64_t p = lane; p < nvec; p += 64) {
+          T xv[V];
+          Ld<T, V>::load(xv, xs + p * V);
+#pragma unroll
+          for (int c = 0; c < kTCols; ++c) {
+            if (j0 + c < cols) {
+              T a[V];
+              Ld<T, V>::load(a, Ap + c * lda + p * V);
+#pragma unroll
+              for (int v = 0; v < V; ++v) acc[c] += a[v] * xv[v];
+            }
+          }
+        }
+        for (int64_t i = nvec * V + lane; i < nr; i += 64) {
+          const T xv = xs[i];
+#pragma unroll
+          for (int c = 0; c < kTCols; ++c)
+            if (j0 + c < cols) acc[c] += Ap[c * lda + i] * xv;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kTCols; ++c) {
+      T s = WaveSumT(acc[c]);
+      if (lane == 0 && j0 + c < cols) {
+        const int64_t j = j0 + c;
+        y[j] = (beta == T(0)) ? alpha * s : alpha * s + beta * y[j];
+      }
+    }
+  }
+}
+
+template <class T>
+void LaunchGemvT(int64_t rows, int64_t cols, double alpha, const T* A, int64_t lda, const T* x,
+                 double beta, T* y) {
+  hipStream_t s = Runtime::Get().stream();
+  constexpr int VV = VT<T>::V;
+  const bool vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % VV == 0);
+  const int64_t cols_per_pass = (kBlock / 64) * kTCols;
+  int64_t npass = (cols + cols_per_pass - 1) / cols_per_pass;
+  int64_t grid = npass < 1024 ? npass : 1024;
+  if (grid < 1) grid = 1;
+  if (vec) {
+    hipLaunchKernelGGL((GemvTKernel<T, VV>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                       s, rows, cols, A, lda, x, T(alpha), T(beta), y);
+  } else {
+    hipLaunchKernelGGL((GemvTKernel<T, 1>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, s,
+                       rows, cols, A, lda, x, T(alpha), T(beta), y);
+  }
+}
+
+}  // namespace
+
+void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, int64_t lda,
+          const DVec& x, double beta, const DVec& y) {
+  EPS_CHECK(A.dt == x.dt && A.dt == y.dt);
+  EPS_CHECK_MSG(lda >= rows, "gemv: lda < rows");
+  EPS_CHECK_MSG(cols == 0 || A.n >= (cols - 1) * lda + rows, "gemv: matrix buffer too small");
+  EPS_CHECK_MSG(x.n == (trans ? rows : cols), "gemv: x has " << x.n << " entries");
+  EPS_CHECK_MSG(y.n == (trans ? cols : rows), "gemv: y has " << y.n << " entries");
+  EPS_CHECK_MSG(x.data() != y.data(), "gemv: x and y alias");
+  if (y.n == 0) return;
+  if (rows == 0 || cols == 0) {
+    if (beta == 0) Fill(y, 0.0);
+    else Axpby(y, beta, y, 0.0);  // y = beta*y
+    return;
+  }
+  if (A.dt == F32) {
+    if (trans) LaunchGemvT<float>(rows, cols, alpha, A.as<float>(), lda, x.as<float>(), beta, y.as<float>());
+    else LaunchGemvN<float>(rows, cols, alpha, A.as<float>(), lda, x.as<float>(), beta, y.as<float>());
+  } else {
+    if (trans) LaunchGemvT<double>(rows, cols, alpha, A.as<double>(), lda, x.as<double>(), beta, y.as<double>());
+    else LaunchGemvN<double>(rows, cols, alpha, A.as<double>(), lda, x.as<double>(), beta, y.as<double>());
+  }
+}
+
+}  // namespace k
+}  // namespace eps

@@ -1,0 +1,214 @@
+// K6 / K9 / K12: proximal-operator kernels.
+//
+//  ScaledZone  - two-sided soft threshold with dead zone, the one kernel behind NORM_1,
+//                SUM_DEADZONE, SUM_HINGE and SUM_QUANTILE
+//                (reference src/epsilon/prox/scaled_zone.cc:78-104).  Branch order is kept
+//                exactly as in the reference so that the selected branch - and therefore the
+//                result for a given input - is bit-identical.
+//  MaxZero     - projection onto R+ (reference prox/non_negative.cc:8), bit-exact.
+//  Norm2Shrink - group soft threshold (reference prox/norm_2.cc:11-16); the norm is read from
+//                a device slot so no host sync sits inside the ADMM sweep.
+//  Tv1d        - exact 1-D total-variation prox (reference prox/total_variation_1d.cc:21 ->
+//                glmgen tf_dp, Johnson's dynamic program).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int GridFor(int64_t n) {
+  int64_t g = (n + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return static_cast<int>(g);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void ScaledZoneKernel(
+    T* x, const T* v, int64_t n, T lam_s, T alpha_s, T beta_s, T M, T C, const T* lam_v,
+    const T* alpha_v, const T* beta_v, int64_t period) {
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n; i += stride) {
+    const int64_t pi = period > 0 ? (i % period) : i;
+    const T lam = lam_v ? lam_v[pi] : lam_s;
+    const T alpha = alpha_v ? alpha_v[pi] : alpha_s;
+    const T beta = beta_v ? beta_v[pi] : beta_s;
+    T xi = v[i] - C;
+    T out;
+    if (fabs(xi) <= M) out = xi;
+    else if (xi > M + lam * alpha) out = xi - lam * alpha;
+    else if (xi < -M - lam * beta) out = xi + lam * beta;
+    else if (xi > T(0)) out = M;
+    else out = -M;
+    x[i] = out;
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void MaxZeroKernel(T* x, const T* v, int64_t n) {
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n; i += stride) {
+    const T vi = v[i];
+    x[i] = vi > T(0) ? vi : T(0);
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void Norm2ShrinkKernel(T* x, const T* v, int64_t n,
+                                                            double lam, const double* normsq) {
+  const double nv = sqrt(*normsq);
+  const T scale = (nv >= lam) ? static_cast<T>(1.0 - lam / nv) : T(0);
+  const bool zero = !(nv >= lam);
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n; i += stride) x[i] = zero ? T(0) : scale * v[i];
+}
+
+// ---- exact 1-D TV prox ---------------------------------------------------------------------
+// Sequential dynamic program (one lane); correctness path for small n.  The knot buffers live
+// in a global workspace `ws` of 8n doubles laid out as x|a|b (2n each) and tm|tp (n each).
+template <class T>
+__global__ void Tv1dSerialKernel(T* beta, const T* y, int64_t n, double lam, double* ws) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (n == 0) return;
+  if (n == 1 || lam == 0) {
+    for (int64_t i = 0; i < n; ++i) beta[i] = y[i];
+    return;
+  }
+  double* x = ws;
+  double* a = ws + 2 * n;
+  double* b = ws + 4 * n;
+  double* tm = ws + 6 * n;
+  double* tp = ws + 7 * n;
+  double y0 = static_cast<double>(y[0]), y1 = static_cast<double>(y[1]);
+  tm[0] = -lam + y0;
+  tp[0] = lam + y0;
+  int64_t lo_i = n - 1, hi_i = n;
+  x[lo_i] = tm[0];
+  x[hi_i] = tp[0];
+  a[lo_i] = 1;
+  b[lo_i] = -y0 + lam;
+  a[hi_i] = -1;
+  b[hi_i] = y0 + lam;
+  double afirst = 1, bfirst = -lam - y1, alast = -1, blast = -lam + y1;
+  for (int64_t k = 1; k < n - 1; ++k) {
+    double alo = afirst, blo = bfirst;
+    int64_t lo = lo_i;
+    for (; lo <= hi_i; ++lo) {
+      if (alo * x[lo] + blo > -lam) break;
+      alo += a[lo];
+      blo += b[lo];
+    }
+    tm[k] = (-lam - blo) / alo;
+    lo_i = lo - 1;
+    x[lo_i] = tm[k];
+    double ahi = alast, bhi = blast;
+    int64_t hi = hi_i;
+    for (; hi >= lo_i; --hi) {
+      if (-ahi * x[hi] - bhi < lam) break;
+      ahi += a[hi];
+      bhi += b[hi];
+    }
+    tp[k] = (lam + bhi) / (-ahi);
+    hi_i = hi + 1;
+    x[hi_i] = tp[k];
+    a[lo_i] = alo;
+    b[lo_i] = blo + lam;
+    a[hi_i] = ahi;
+    b[hi_i] = bhi + lam;
+    const double yk1 = static_cast<double>(y[k + 1]);
+    afirst = 1;
+    bfirst = -lam - yk1;
+    alast = -1;
+    blast = -lam + yk1;
+  }
+  double alo = afirst, blo = bfirst;
+  for (int64_t lo = lo_i; lo <= hi_i; ++lo) {
+    if (alo * x[lo] + blo > 0) break;
+    alo += a[lo];
+    blo += b[lo];
+  }
+  double bn = -blo / alo;
+  beta[n - 1] = static_cast<T>(bn);
+  for (int64_t k = n - 2; k >= 0; --k) {
+    if (bn > tp[k]) bn = tp[k];
+    else if (bn < tm[k]) bn = tm[k];
+    beta[k] = static_cast<T>(bn);
+  }
+}
+
+}  // namespace
+
+void ScaledZone(const DVec& x, const DVec& v, const ScaledZoneArgs& g) {
+  EPS_CHECK(x.n == v.n && x.dt == v.dt);
+  const int64_t n = x.n;
+  if (n == 0) return;
+  const int64_t need = g.period > 0 ? g.period : n;
+  if (g.lam_vec) EPS_CHECK(g.lam_vec->n >= need && g.lam_vec->dt == x.dt);
+  if (g.alpha_vec) EPS_CHECK(g.alpha_vec->n >= need && g.alpha_vec->dt == x.dt);
+  if (g.beta_vec) EPS_CHECK(g.beta_vec->n >= need && g.beta_vec->dt == x.dt);
+  hipStream_t s = Runtime::Get().stream();
+  if (x.dt == F32) {
+    using T = float;
+    hipLaunchKernelGGL(ScaledZoneKernel<T>, dim3(GridFor(n)), dim3(kBlock), 0, s, x.as<T>(),
+                       v.as<T>(), n, T(g.lam), T(g.alpha), T(g.beta), T(g.M), T(g.C),
+                       g.lam_vec ? g.lam_vec->as<T>() : nullptr,
+                       g.alpha_vec ? g.alpha_vec->as<T>() : nullptr,
+                       g.beta_vec ? g.beta_vec->as<T>() : nullptr, g.period);
+  } else {
+    using T = double;
+    hipLaunchKernelGGL(ScaledZoneKernel<T>, dim3(GridFor(n)), dim3(kBlock), 0, s, x.as<T>(),
+                       v.as<T>(), n, T(g.lam), T(g.alpha), T(g.beta), T(g.M), T(g.C),
+                       g.lam_vec ? g.lam_vec->as<T>() : nullptr,
+                       g.alpha_vec ? g.alpha_vec->as<T>() : nullptr,
+                       g.beta_vec ? g.beta_vec->as<T>() : nullptr, g.period);
+  }
+}
+
+void MaxZero(const DVec& x, const DVec& v) {
+  EPS_CHECK(x.n == v.n && x.dt == v.dt);
+  if (x.n == 0) return;
+  hipStream_t s = Runtime::Get().stream();
+  if (x.dt == F32)
+    hipLaunchKernelGGL(MaxZeroKernel<float>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
+                       x.as<float>(), v.as<float>(), x.n);
+  else
+    hipLaunchKernelGGL(MaxZeroKernel<double>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
+                       x.as<double>(), v.as<double>(), x.n);
+}
+
+void Norm2Shrink(const DVec& x, const DVec& v, double lam, const double* normsq) {
+  EPS_CHECK(x.n == v.n && x.dt == v.dt);
+  if (x.n == 0) return;
+  hipStream_t s = Runtime::Get().stream();
+  if (x.dt == F32)
+    hipLaunchKernelGGL(Norm2ShrinkKernel<float>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
+                       x.as<float>(), v.as<float>(), x.n, lam, normsq);
+  else
+    hipLaunchKernelGGL(Norm2ShrinkKernel<double>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
+                       x.as<double>(), v.as<double>(), x.n, lam, normsq);
+}
+
+void Tv1d(const DVec& x, const DVec& v, double lam) {
+  EPS_CHECK(x.n == v.n && x.dt == v.dt);
+  const int64_t n = x.n;
+  if (n == 0) return;
+  Runtime& rt = Runtime::Get();
+  auto ws = rt.Alloc(static_cast<size_t>(8 * n) * sizeof(double));
+  if (x.dt == F32)
+    hipLaunchKernelGGL(Tv1dSerialKernel<float>, dim3(1), dim3(64), 0, rt.stream(), x.as<float>(),
+                       v.as<float>(), n, lam, static_cast<double*>(ws->p));
+  else
+    hipLaunchKernelGGL(Tv1dSerialKernel<double>, dim3(1), dim3(64), 0, rt.stream(),
+                       x.as<double>(), v.as<double>(), n, lam, static_cast<double*>(ws->p));
+}
+
+}  // namespace k
+}  // namespace eps

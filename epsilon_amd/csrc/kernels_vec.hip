@@ -1,0 +1,398 @@
+// K7 / K8: streaming vector kernels and deterministic reductions for gfx950.
+//
+// All of these are HBM-bound: 16 B per lane per access (float4 / double2) when the operands
+// are 16-byte aligned, grid capped at 2048 workgroups with a grid-stride loop
+// (cdna_hip_programming.md Guidelines 11 and 13).  Reductions accumulate in fp64, reduce a
+// wave with shuffles (64 lanes), the workgroup through LDS, and finish in a fixed order so
+// that two runs give identical bits (no float atomics).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 2048;
+
+template <class T> struct Pack;
+template <> struct Pack<float> { using type = float4; static constexpr int V = 4; };
+template <> struct Pack<double> { using type = double2; static constexpr int V = 2; };
+
+inline bool Aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int GridFor(int64_t work_items) {
+  int64_t g = (work_items + kBlock - 1) / kBlock;
+  if (g < 1) g = 1;
+  if (g > kMaxGrid) g = kMaxGrid;
+  return static_cast<int>(g);
+}
+
+// ---- generic elementwise: y[i] = f(a[i], b[i], c[i], i) -------------------------------------
+
+template <class T, class F, bool VEC>
+__global__ __launch_bounds__(kBlock) void EwKernel(T* y, const T* a, const T* b,
+                                                   const T* c, int64_t n, F f) {
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  if (VEC) {
+    using P = typename Pack<T>::type;
+    constexpr int V = Pack<T>::V;
+    const int64_t npack = n / V;
+    for (int64_t p = tid; p < npack; p += stride) {
+      T av[V], bv[V], cv[V], yv[V];
+      if (a) *reinterpret_cast<P*>(av) = reinterpret_cast<const P*>(a)[p];
+      if (b) *reinterpret_cast<P*>(bv) = reinterpret_cast<const P*>(b)[p];
+      if (c) *reinterpret_cast<P*>(cv) = reinterpret_cast<const P*>(c)[p];
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        yv[j] = f(a ? av[j] : T(0), b ? bv[j] : T(0), c ? cv[j] : T(0), p * V + j);
+      reinterpret_cast<P*>(y)[p] = *reinterpret_cast<P*>(yv);
+    }
+    for (int64_t i = npack * V + tid; i < n; i += stride)
+      y[i] = f(a ? a[i] : T(0), b ? b[i] : T(0), c ? c[i] : T(0), i);
+  } else {
+    for (int64_t i = tid; i < n; i += stride)
+      y[i] = f(a ? a[i] : T(0), b ? b[i] : T(0), c ? c[i] : T(0), i);
+  }
+}
+
+template <class T, class F>
+void LaunchEw(T* y, const T* a, const T* b, const T* c, int64_t n, F f) {
+  if (n <= 0) return;
+  hipStream_t s = Runtime::Get().stream();
+  bool vec = Aligned16(y) && (!a || Aligned16(a)) && (!b || Aligned16(b)) &&
+             (!c || Aligned16(c)) && n >= 4 * Pack<T>::V;
+  if (vec) {
+    int grid = GridFor(n / Pack<T>::V);
+    hipLaunchKernelGGL((EwKernel<T, F, true>), dim3(grid), dim3(kBlock), 0, s, y, a, b, c, n, f);
+  } else {
+    int grid = GridFor(n);
+    hipLaunchKernelGGL((EwKernel<T, F, false>), dim3(grid), dim3(kBlock), 0, s, y, a, b, c, n,
+                       f);
+  }
+}
+
+template <class T> struct FillF {
+  T v;
+  __device__ T operator()(T, T, T, int64_t) const { return v; }
+};
+template <class T> struct ScaleF {  // y = a*x
+  T a;
+  __device__ T operator()(T x, T, T, int64_t) const { return a * x; }
+};
+template <class T> struct AxpbyF {  // y = a*x + b*y   (x in slot a, y in slot b)
+  T a, b;
+  __device__ T operator()(T x, T y, T, int64_t) const { return a * x + b * y; }
+};
+template <class T> struct AddF {  // y = y + x  /  y = y - x with exact single rounding
+  T sign;
+  __device__ T operator()(T x, T y, T, int64_t) const { return y + sign * x; }
+};
+template <class T> struct DiagMulF {  // y = a*d*x + b*y
+  T a, b;
+  __device__ T operator()(T d, T x, T y, int64_t) const { return a * (d * x) + b * y; }
+};
+template <class T> struct DiagMul0F {  // y = a*d*x
+  T a;
+  __device__ T operator()(T d, T x, T, int64_t) const { return a * (d * x); }
+};
+template <class T> struct CopyF {
+  __device__ T operator()(T x, T, T, int64_t) const { return x; }
+};
+
+void CheckSame(const DVec& a, const DVec& b) {
+  EPS_CHECK_MSG(a.n == b.n, "vector length mismatch " << a.n << " vs " << b.n);
+  EPS_CHECK_MSG(a.dt == b.dt, "vector dtype mismatch");
+}
+
+// ---- conversion kernels ---------------------------------------------------------------------
+
+template <class D, class S>
+__global__ __launch_bounds__(kBlock) void CvtKernel(D* __restrict__ dst, const S* __restrict__ src,
+                                                    int64_t n) {
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = tid; i < n; i += stride) dst[i] = static_cast<D>(src[i]);
+}
+
+template <class D, class S> void LaunchCvt(D* dst, const S* src, int64_t n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL((CvtKernel<D, S>), dim3(GridFor(n)), dim3(kBlock), 0,
+                     Runtime::Get().stream(), dst, src, n);
+}
+
+// ---- reductions -----------------------------------------------------------------------------
+
+__device__ inline double WaveSum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over the workgroup; result valid in thread 0.
+__device__ inline double BlockSum(double v) {
+  __shared__ double wsum[kBlock / 64];
+  v = WaveSum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wsum[wave] = v;
+  __syncthreads();
+  double total = 0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) total += wsum[w];
+  }
+  __syncthreads();
+  return total;
+}
+
+enum RedOp { RED_SUMSQ = 0, RED_SUMSQ_DIFF = 1, RED_DOT = 2 };
+
+template <class T, int OP>
+__device__ inline double RedTerm(const T* x, const T* y, int64_t i) {
+  if (OP == RED_SUMSQ) {
+    double a = static_cast<double>(x[i]);
+    return a * a;
+  } else if (OP == RED_SUMSQ_DIFF) {
+    double a = static_cast<double>(x[i]) - static_cast<double>(y[i]);
+    return a * a;
+  } else {
+    return static_cast<double>(x[i]) * static_cast<double>(y[i]);
+  }
+}
+
+// Stage 1: partial[blockIdx] = sum over this block's grid-stride share.
+// If gridDim.x == 1 the result goes straight to the slot.
+template <class T, int OP>
+__global__ __launch_bounds__(kBlock) void RedKernel(const T* __restrict__ x,
+                                                    const T* __restrict__ y, int64_t n,
+                                                    double* partial, double* slot,
+                                                    int accumulate) {
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double acc = 0;
+  for (int64_t i = tid; i < n; i += stride) acc += RedTerm<T, OP>(x, y, i);
+  double total = BlockSum(acc);
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) {
+      *slot = (accumulate ? *slot : 0.0) + total;
+    } else {
+      partial[blockIdx.x] = total;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void RedFinalKernel(const double* partial, int nparts,
+                                                         double* slot, int accumulate) {
+  double acc = 0;
+  for (int i = threadIdx.x; i < nparts; i += kBlock) acc += partial[i];
+  double total = BlockSum(acc);
+  if (threadIdx.x == 0) *slot = (accumulate ? *slot : 0.0) + total;
+}
+
+template <class T, int OP>
+void LaunchRed(const T* x, const T* y, int64_t n, double* slot, bool accumulate) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  if (n <= (int64_t(1) << 17)) {
+    hipLaunchKernelGGL((RedKernel<T, OP>), dim3(1), dim3(kBlock), 0, s, x, y, n,
+                       static_cast<double*>(nullptr), slot, accumulate ? 1 : 0);
+    return;
+  }
+  int grid = GridFor(n / 8);
+  if (grid > 1024) grid = 1024;
+  double* partial = static_cast<double*>(rt.Scratch(1024 * sizeof(double)));
+  hipLaunchKernelGGL((RedKernel<T, OP>), dim3(grid), dim3(kBlock), 0, s, x, y, n, partial, slot,
+                     0);
+  hipLaunchKernelGGL(RedFinalKernel, dim3(1), dim3(kBlock), 0, s, partial, grid, slot,
+                     accumulate ? 1 : 0);
+}
+
+// ---- small dense helpers --------------------------------------------------------------------
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void AddDiagKernel(T* W, int64_t n, int64_t ld, T alpha,
+                                                        const T* d) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  if (i < n) W[i + i * ld] += d ? alpha * d[i] : alpha;
+}
+
+// dst[i + j*rows] = alpha * (trans ? src[j + i*lds] : src[i + j*lds]); 32x32 LDS tile transpose
+template <class T>
+__global__ __launch_bounds__(kBlock) void MatCopyKernel(int trans, int64_t rows, int64_t cols,
+                                                        T alpha, const T* __restrict__ src,
+                                                        int64_t lds, T* __restrict__ dst) {
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * 32, j0 = static_cast<int64_t>(blockIdx.y) * 32;
+  if (!trans) {
+    for (int r = ty; r < 32; r += 8) {
+      int64_t i = i0 + tx, j = j0 + r;
+      if (i < rows && j < cols) dst[i + j * rows] = alpha * src[i + j * lds];
+    }
+    return;
+  }
+  // src is cols x rows (ld lds); read coalesced along src's first index (= dst column j)
+  for (int r = ty; r < 32; r += 8) {
+    int64_t j = j0 + tx, i = i0 + r;
+    if (i < rows && j < cols) tile[r][tx] = src[j + i * lds];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int64_t i = i0 + tx, j = j0 + r;
+    if (i < rows && j < cols) dst[i + j * rows] = alpha * tile[tx][r];
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void SymmetrizeKernel(T* C, int64_t n, int64_t ldc) {
+  // upper(i<j) := lower(j,i); tile (bi, bj) with bi <= bj handled via LDS transpose
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t bi = blockIdx.x, bj = blockIdx.y;
+  if (bi > bj) return;
+  // read lower tile rows j-range, cols i-range: element (j, i), j in bj-tile, i in bi-tile
+  for (int r = ty; r < 32; r += 8) {
+    int64_t jj = bj * 32 + tx, ii = bi * 32 + r;
+    if (jj < n && ii < n) tile[r][tx] = C[jj + ii * ldc];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int64_t ii = bi * 32 + tx, jj = bj * 32 + r;
+    if (ii < n && jj < n && ii < jj) C[ii + jj * ldc] = tile[tx][r];
+  }
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void KronKernel(T* __restrict__ dst, const T* __restrict__ A,
+                                                     int64_t mA, int64_t nA,
+                                                     const T* __restrict__ B, int64_t mB,
+                                                     int64_t nB) {
+  const int64_t M = mA * mB, N = nA * nB;
+  const int64_t total = M * N;
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t idx = tid; idx < total; idx += stride) {
+    int64_t r = idx % M, c = idx / M;
+    int64_t ia = r / mB, ib = r % mB, ja = c / nB, jb = c % nB;
+    dst[idx] = A[ia + ja * mA] * B[ib + jb * mB];
+  }
+}
+
+}  // namespace
+
+#define EPS_DISPATCH(dt, ...)                      \
+  do {                                             \
+    if ((dt) == F32) {                             \
+      using T = float;                             \
+      __VA_ARGS__;                                 \
+    } else {                                       \
+      using T = double;                            \
+      __VA_ARGS__;                                 \
+    }                                              \
+  } while (0)
+
+void Fill(const DVec& y, double v) {
+  EPS_DISPATCH(y.dt, LaunchEw<T>(y.as<T>(), nullptr, nullptr, nullptr, y.n, FillF<T>{T(v)}));
+}
+
+void Copy(const DVec& dst, const DVec& src) {
+  CheckSame(dst, src);
+  if (dst.n == 0 || dst.data() == src.data()) return;
+  EPS_HIP(hipMemcpyAsync(dst.data(), src.data(), dst.bytes(), hipMemcpyDeviceToDevice,
+                         Runtime::Get().stream()));
+}
+
+void Axpby(const DVec& y, double a, const DVec& x, double b) {
+  CheckSame(y, x);
+  if (b == 0) {
+    EPS_DISPATCH(y.dt, LaunchEw<T>(y.as<T>(), x.as<T>(), nullptr, nullptr, y.n, ScaleF<T>{T(a)}));
+  } else if (b == 1 && (a == 1 || a == -1)) {
+    EPS_DISPATCH(y.dt,
+                 LaunchEw<T>(y.as<T>(), x.as<T>(), y.as<T>(), nullptr, y.n, AddF<T>{T(a)}));
+  } else {
+    EPS_DISPATCH(y.dt, LaunchEw<T>(y.as<T>(), x.as<T>(), y.as<T>(), nullptr, y.n,
+                                   AxpbyF<T>{T(a), T(b)}));
+  }
+}
+
+void DiagMul(const DVec& y, double a, const DVec& d, const DVec& x, double b) {
+  CheckSame(y, x);
+  CheckSame(y, d);
+  if (b == 0) {
+    EPS_DISPATCH(y.dt,
+                 LaunchEw<T>(y.as<T>(), d.as<T>(), x.as<T>(), nullptr, y.n, DiagMul0F<T>{T(a)}));
+  } else {
+    EPS_DISPATCH(y.dt, LaunchEw<T>(y.as<T>(), d.as<T>(), x.as<T>(), y.as<T>(), y.n,
+                                   DiagMulF<T>{T(a), T(b)}));
+  }
+}
+
+void ConvertFromF64(const DVec& dst, const double* src_dev) {
+  EPS_DISPATCH(dst.dt, LaunchCvt<T, double>(dst.as<T>(), src_dev, dst.n));
+}
+
+void ConvertFromF32(const DVec& dst, const float* src_dev) {
+  EPS_DISPATCH(dst.dt, LaunchCvt<T, float>(dst.as<T>(), src_dev, dst.n));
+}
+
+void ConvertToF64(double* dst_dev, const DVec& src) {
+  EPS_DISPATCH(src.dt, LaunchCvt<double, T>(dst_dev, src.as<T>(), src.n));
+}
+
+void SumSq(const DVec& x, double* slot, bool accumulate) {
+  EPS_DISPATCH(x.dt, (LaunchRed<T, RED_SUMSQ>(x.as<T>(), nullptr, x.n, slot, accumulate)));
+}
+
+void SumSqDiff(const DVec& x, const DVec& y, double* slot, bool accumulate) {
+  CheckSame(x, y);
+  EPS_DISPATCH(x.dt, (LaunchRed<T, RED_SUMSQ_DIFF>(x.as<T>(), y.as<T>(), x.n, slot, accumulate)));
+}
+
+void Dot(const DVec& x, const DVec& y, double* slot, bool accumulate) {
+  CheckSame(x, y);
+  EPS_DISPATCH(x.dt, (LaunchRed<T, RED_DOT>(x.as<T>(), y.as<T>(), x.n, slot, accumulate)));
+}
+
+void AddDiag(const DVec& W, int64_t n, int64_t ld, double alpha, const DVec* d) {
+  if (n <= 0) return;
+  EPS_CHECK(W.n >= (n - 1) * ld + n);
+  if (d) EPS_CHECK(d->n == n && d->dt == W.dt);
+  int grid = static_cast<int>((n + kBlock - 1) / kBlock);
+  EPS_DISPATCH(W.dt, hipLaunchKernelGGL(AddDiagKernel<T>, dim3(grid), dim3(kBlock), 0,
+                                        Runtime::Get().stream(), W.as<T>(), n, ld, T(alpha),
+                                        d ? d->as<T>() : static_cast<const T*>(nullptr)));
+}
+
+void MatCopy(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& src,
+             int64_t lds, const DVec& dst) {
+  if (rows <= 0 || cols <= 0) return;
+  EPS_CHECK(dst.n >= rows * cols && src.dt == dst.dt);
+  dim3 grid(static_cast<unsigned>((rows + 31) / 32), static_cast<unsigned>((cols + 31) / 32));
+  EPS_DISPATCH(dst.dt, hipLaunchKernelGGL(MatCopyKernel<T>, grid, dim3(kBlock), 0,
+                                          Runtime::Get().stream(), trans ? 1 : 0, rows, cols,
+                                          T(alpha), src.as<T>(), lds, dst.as<T>()));
+}
+
+void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc) {
+  if (n <= 1) return;
+  unsigned nb = static_cast<unsigned>((n + 31) / 32);
+  EPS_DISPATCH(C.dt, hipLaunchKernelGGL(SymmetrizeKernel<T>, dim3(nb, nb), dim3(kBlock), 0,
+                                        Runtime::Get().stream(), C.as<T>(), n, ldc));
+}
+
+void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVec& B,
+               int64_t mB, int64_t nB) {
+  int64_t total = mA * mB * nA * nB;
+  EPS_CHECK(dst.n == total && A.n >= mA * nA && B.n >= mB * nB);
+  EPS_CHECK(dst.dt == A.dt && dst.dt == B.dt);
+  if (total == 0) return;
+  EPS_DISPATCH(dst.dt, hipLaunchKernelGGL(KronKernel<T>, dim3(GridFor(total)), dim3(kBlock), 0,
+                                          Runtime::Get().stream(), dst.as<T>(), A.as<T>(), mA,
+                                          nA, B.as<T>(), mB, nB));
+}
+
+}  // namespace k
+}  // namespace eps

@@ -1,0 +1,383 @@
+#include "prox.h"
+
+#include <cmath>
+#include <map>
+
+#include "kernels.h"
+
+namespace eps {
+
+// ---- registry (reference prox/prox.cc:25-45, prox.h:51-77) -----------------------------------------
+
+namespace {
+using Factory = std::function<std::unique_ptr<ProxOperator>()>;
+std::map<std::pair<int, bool>, Factory>* g_registry = nullptr;
+}  // namespace
+
+bool RegisterProxOperatorFactory(int type, bool epigraph, Factory factory) {
+  if (g_registry == nullptr) g_registry = new std::map<std::pair<int, bool>, Factory>();
+  (*g_registry)[std::make_pair(type, epigraph)] = std::move(factory);
+  return true;
+}
+
+std::unique_ptr<ProxOperator> CreateProxOperator(int type, bool epigraph) {
+  EPS_CHECK_MSG(g_registry != nullptr, "No registered operators");
+  auto it = g_registry->find(std::make_pair(type, epigraph));
+  if (it == g_registry->end()) {
+    EPS_FATAL("No proximal operator for " << pb::ProxTypeName(type) << " (epigraph: " << epigraph
+                                          << ")");
+  }
+  return it->second();
+}
+
+// ---- VectorProx (reference prox/vector_prox.cc) ------------------------------------------------------
+
+namespace {
+
+bool GetScalarBM(const BlockMatrix& A, double* alpha) {  // vector_prox.cc:4-26
+  bool first = true;
+  for (const auto& col : A.data()) {
+    if (col.second.size() != 1 || col.first != col.second.begin()->first) return false;
+    const LinearMap& Ai = col.second.begin()->second;
+    if (Ai.impl().type() != SCALAR_MATRIX) return false;
+    const double a = GetScalar(Ai);
+    if (first) {
+      *alpha = a;
+      first = false;
+    } else if (*alpha != a) {
+      return false;
+    }
+  }
+  return true;
+}
+
+bool GetDiagonalBM(const BlockMatrix& A, std::vector<double>* alpha) {  // vector_prox.cc:28-49
+  bool first = true;
+  for (const auto& col : A.data()) {
+    if (col.second.size() != 1 || col.first != col.second.begin()->first) return false;
+    const LinearMap& Ai = col.second.begin()->second;
+    if (Ai.impl().type() != SCALAR_MATRIX && Ai.impl().type() != DIAGONAL_MATRIX) return false;
+    std::vector<double> a = GetDiagonal(Ai);
+    if (first) {
+      *alpha = a;
+      first = false;
+    } else if (*alpha != a) {
+      return false;
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
+double VectorProxInput::lambda() const {
+  EPS_CHECK_MSG(!elementwise_, "scalar lambda requested from an elementwise-scaled prox");
+  return lambda_;
+}
+
+const DVec& VectorProxInput::value_vec(int i) const { return v_(affine::arg_key(i)); }
+
+void VectorProxOutput::set_value(int i, DVec x) { x_.Set(affine::arg_key(i), std::move(x)); }
+
+bool VectorProx::InitScalar(const ProxOperatorArg& arg) {  // vector_prox.cc:51-70
+  const double alpha = arg.prox_function().alpha;
+  const BlockMatrix& H = arg.affine_arg().A;
+  const BlockMatrix& A = arg.affine_constraint().A;
+  BlockMatrix HT = H.Transpose();
+  BlockMatrix AT = A.Transpose();
+  double beta, gamma;
+  if (!GetScalarBM(HT * H, &beta) || !GetScalarBM(H * AT * A * HT, &gamma)) return false;
+  B_ = (beta / gamma) * H * AT;
+  C_ = (1 / beta) * HT;
+  D_ = BlockMatrix();
+  input_.lambda_ = alpha * beta * beta / gamma;
+  input_.lambda_host_.clear();
+  input_.lambda_dev_ = DVec();
+  input_.elementwise_ = false;
+  EPS_CHECK(input_.lambda_ >= 0);
+  return true;
+}
+
+bool VectorProx::InitDiagonal(const ProxOperatorArg& arg) {  // vector_prox.cc:72-118
+  const double alpha = arg.prox_function().alpha;
+  const BlockMatrix& H = arg.affine_arg().A;
+  const BlockMatrix& A = arg.affine_constraint().A;
+  BlockMatrix HT = H.Transpose();
+  BlockMatrix AT = A.Transpose();
+  std::vector<double> beta, gamma;
+  if (!GetDiagonalBM(HT * H, &beta) || !GetDiagonalBM(H * AT * A * HT, &gamma)) return false;
+  const size_t n = beta.size();
+  EPS_CHECK(gamma.size() == n);
+  std::vector<double> lambda(n), delta(n, 0.0), bq(n), binv(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (gamma[i]) {
+      lambda[i] = alpha * beta[i] * beta[i] / gamma[i];
+    } else {  // zero weight: the variable is unconstrained by f, keep the prox centre
+      lambda[i] = 0;
+      beta[i] = 1;
+      gamma[i] = 1;
+      delta[i] = 1;
+    }
+    bq[i] = beta[i] / gamma[i];
+    binv[i] = 1 / beta[i];
+  }
+  const DType dt = arg.data_map()->dtype();
+  LinearMap B0 = LinearMap::Diagonal(bq, dt);
+  LinearMap C0 = LinearMap::Diagonal(binv, dt);
+  LinearMap D0 = LinearMap::Diagonal(delta, dt);
+  BlockMatrix B_scale, C_scale, D_scale;
+  for (const std::string& key : H.col_keys()) {
+    B_scale(key, key) = B0;
+    C_scale(key, key) = C0;
+    D_scale(key, key) = D0;
+  }
+  B_ = H * B_scale * AT;
+  C_ = C_scale * HT;
+  D_ = (AT * A).Inverse() * D_scale * AT;
+  input_.lambda_host_ = lambda;
+  input_.lambda_dev_ = DVec::FromHost(lambda.data(), static_cast<int64_t>(n), dt);
+  input_.elementwise_ = true;
+  return true;
+}
+
+void VectorProx::Init(const ProxOperatorArg& arg) {  // vector_prox.cc:120-138
+  if (!InitScalar(arg) && !InitDiagonal(arg))
+    EPS_FATAL("Affine transformation is not scalar or diagonal");
+  g_ = arg.affine_arg().b;
+  input_.f_ = arg.prox_function();
+}
+
+BlockVector VectorProx::Apply(const BlockVector& v) {  // vector_prox.cc:140-183
+  input_.v_ = B_ * v + g_;
+  output_.x_ = BlockVector();
+  ApplyVector(input_, &output_);
+  BlockVector r = C_ * (output_.x_ - g_);
+  if (!D_.data().empty()) r += D_ * v;
+  return r;
+}
+
+// ---- ScaledZoneProx: NORM_1, SUM_DEADZONE, SUM_HINGE, SUM_QUANTILE -----------------------------------
+// reference prox/scaled_zone.cc:6-121
+
+namespace {
+
+struct ZoneParam {  // a uniform value or a per-element vector
+  double value = 0;
+  DVec vec;
+  bool is_vec = false;
+};
+
+ZoneParam PromoteParam(const DVec& x, int64_t n) {  // scaled_zone.cc:26-32
+  ZoneParam p;
+  if (x.n == n && n != 1) {
+    p.vec = x;
+    p.is_vec = true;
+    return p;
+  }
+  EPS_CHECK_MSG(x.n == 1, "scaled zone parameter has " << x.n << " entries, expected " << n);
+  p.value = x.ToHost()[0];
+  return p;
+}
+
+class ScaledZoneProx final : public VectorProx {
+ public:
+  void Init(const ProxOperatorArg& arg) override {
+    VectorProx::Init(arg);
+    const pb::ProxFunction& f = arg.prox_function();
+    EPS_CHECK_MSG(!f.arg_size.empty() && f.arg_size[0].dim.size() == 2,
+                  "scaled zone prox needs arg_size");
+    if (f.has_axis) n_ = f.arg_size[0].dim[f.axis];
+    else n_ = static_cast<int64_t>(f.arg_size[0].dim[0]) * f.arg_size[0].dim[1];
+    rows_ = f.arg_size[0].dim[0];
+    has_axis_ = f.has_axis;
+    axis_ = f.axis;
+    alpha_.value = 1;
+    beta_.value = 1;
+    switch (f.prox_function_type) {  // scaled_zone.cc:46-72
+      case pb::ProxFunction::NORM_1: break;
+      case pb::ProxFunction::SUM_DEADZONE: M_ = f.sz_m; break;
+      case pb::ProxFunction::SUM_HINGE: beta_.value = 0; break;
+      case pb::ProxFunction::SUM_QUANTILE: {
+        EPS_CHECK_MSG(f.sz_alpha_expr && f.sz_beta_expr, "SUM_QUANTILE needs alpha/beta exprs");
+        BlockVector tmp;
+        affine::BuildAffineOperator(*f.sz_alpha_expr, arg.data_map(), "alpha", nullptr, &tmp);
+        affine::BuildAffineOperator(*f.sz_beta_expr, arg.data_map(), "beta", nullptr, &tmp);
+        alpha_ = PromoteParam(tmp("alpha"), n_);
+        beta_ = PromoteParam(tmp("beta"), n_);
+        break;
+      }
+      default: EPS_FATAL("Unknown prox type: " << f.prox_function_type);
+    }
+  }
+
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = DVec::Empty(v.n, v.dt);
+    k::ScaledZoneArgs a;
+    a.M = M_;
+    a.C = 0;
+    a.alpha = alpha_.value;
+    a.beta = beta_.value;
+    if (alpha_.is_vec) a.alpha_vec = &alpha_.vec;
+    if (beta_.is_vec) a.beta_vec = &beta_.vec;
+    if (input.elementwise()) a.lam_vec = &input.lambda_vec();
+    else a.lam = input.lambda();
+    const bool any_vec = alpha_.is_vec || beta_.is_vec || input.elementwise();
+    if (has_axis_ && any_vec) {
+      // per-slice parameters: slice = a column (axis 0) of the column-major argument
+      EPS_CHECK_MSG(axis_ == 0, "per-element scaled-zone parameters along axis 1 not supported");
+      a.period = rows_;
+    }
+    k::ScaledZone(x, v, a);
+    output->set_value(0, x);
+  }
+
+ private:
+  ZoneParam alpha_, beta_;
+  double M_ = 0;
+  int64_t n_ = 0, rows_ = 0;
+  bool has_axis_ = false;
+  int axis_ = 0;
+};
+REGISTER_PROX_OPERATOR(NORM_1, ScaledZoneProx);
+REGISTER_PROX_OPERATOR(SUM_DEADZONE, ScaledZoneProx);
+REGISTER_PROX_OPERATOR(SUM_HINGE, ScaledZoneProx);
+REGISTER_PROX_OPERATOR(SUM_QUANTILE, ScaledZoneProx);
+
+// ---- Norm2Prox (reference prox/norm_2.cc:4-19) ---------------------------------------------------------
+
+class Norm2Prox final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    EPS_CHECK_MSG(!input.prox_function().has_axis, "NORM_2 with an axis is not supported yet");
+    const DVec& v = input.value_vec(0);
+    if (!normsq_) normsq_ = Runtime::Get().Alloc(sizeof(double));
+    double* slot = static_cast<double*>(normsq_->p);
+    k::SumSq(v, slot, false);
+    DVec x = DVec::Empty(v.n, v.dt);
+    k::Norm2Shrink(x, v, input.lambda(), slot);
+    output->set_value(0, x);
+  }
+
+ private:
+  std::shared_ptr<Buffer> normsq_;
+};
+REGISTER_PROX_OPERATOR(NORM_2, Norm2Prox);
+
+// ---- NonNegativeProx (reference prox/non_negative.cc:3-11) ---------------------------------------------
+
+class NonNegativeProx final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = DVec::Empty(v.n, v.dt);
+    k::MaxZero(x, v);
+    output->set_value(0, x);
+  }
+};
+REGISTER_PROX_OPERATOR(NON_NEGATIVE, NonNegativeProx);
+
+// ---- TotalVariation1DProx (reference prox/total_variation_1d.cc:7-25) ---------------------------------
+
+class TotalVariation1DProx final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = DVec::Empty(v.n, v.dt);
+    k::Tv1d(x, v, input.lambda());
+    output->set_value(0, x);
+  }
+};
+REGISTER_PROX_OPERATOR(TOTAL_VARIATION_1D, TotalVariation1DProx);
+
+// ---- SumSquareProx: ||H(x)||_2^2 (reference prox/sum_square.cc:10-40) ---------------------------------
+
+class SumSquareProx final : public ProxOperator {
+ public:
+  void Init(const ProxOperatorArg& arg) override {
+    const BlockMatrix& H = arg.affine_arg().A;
+    const BlockVector& g = arg.affine_arg().b;
+    const BlockMatrix& A = arg.affine_constraint().A;
+    const double alpha = std::sqrt(2 * arg.prox_function().alpha);
+    // [ 0   H'  A'][ x ] = [ 0 ]
+    // [ H  -I   0 ][ y ]   [-g ]
+    // [ A   0  -I ][ z ]   [ v ]
+    BlockMatrix M = alpha * (H + H.Transpose()) + (A + A.Transpose()) - H.LeftIdentity() -
+                    A.LeftIdentity();
+    chol_.Compute(M);
+    b_ = (-alpha) * g;
+    var_keys_ = H.col_keys();
+  }
+  BlockVector Apply(const BlockVector& v) override {
+    return chol_.Solve(b_ + v).Select(var_keys_);
+  }
+
+ private:
+  BlockCholesky chol_;
+  BlockVector b_;
+  std::set<std::string> var_keys_;
+};
+REGISTER_PROX_OPERATOR(SUM_SQUARE, SumSquareProx);
+
+// ---- ZeroProx: I(H(x) = 0) (reference prox/zero.cc:10-36) ---------------------------------------------
+
+class ZeroProx final : public ProxOperator {
+ public:
+  void Init(const ProxOperatorArg& arg) override {
+    const BlockMatrix& H = arg.affine_arg().A;
+    const BlockVector& g = arg.affine_arg().b;
+    const BlockMatrix& A = arg.affine_constraint().A;
+    BlockMatrix M = H + H.Transpose() + A + A.Transpose() - A.LeftIdentity();
+    chol_.Compute(M);
+    b_ = (-1.0) * g;
+    var_keys_ = H.col_keys();
+  }
+  BlockVector Apply(const BlockVector& v) override {
+    return chol_.Solve(b_ + v).Select(var_keys_);
+  }
+
+ private:
+  BlockCholesky chol_;
+  BlockVector b_;
+  std::set<std::string> var_keys_;
+};
+REGISTER_PROX_OPERATOR(ZERO, ZeroProx);
+
+// ---- AffineProx: c'x (reference prox/affine.cc:8-49) ---------------------------------------------------
+
+class AffineProx final : public ProxOperator {
+ public:
+  void Init(const ProxOperatorArg& arg) override {
+    const BlockMatrix& A = arg.affine_constraint().A;
+    const BlockVector& b = arg.affine_constraint().b;
+    const double alpha = arg.prox_function().alpha;
+    BlockVector c;
+    if (arg.prox_function().prox_function_type == pb::ProxFunction::AFFINE) {
+      // GetLinear (affine.cc:8-17): the 1 x n maps of H as vectors
+      const DType dt = arg.data_map()->dtype();
+      for (const auto& col : arg.affine_arg().A.data()) {
+        for (const auto& row : col.second) {
+          EPS_CHECK_MSG(row.second.impl().m() == 1, "AFFINE prox expects 1 x n argument maps");
+          auto D = ToDense(row.second.impl(), dt);
+          c.Set(col.first, D->Materialize(false));  // 1 x n contiguous == the transposed row
+        }
+      }
+      c = alpha * c;
+    }
+    BlockMatrix M = A + A.Transpose() - A.LeftIdentity();
+    chol_.Compute(M);
+    g_ = (-1.0) * b - c;
+  }
+  BlockVector Apply(const BlockVector& v) override { return chol_.Solve(g_ + v); }
+
+ private:
+  BlockCholesky chol_;
+  BlockVector g_;
+};
+REGISTER_PROX_OPERATOR(AFFINE, AffineProx);
+REGISTER_PROX_OPERATOR(CONSTANT, AffineProx);
+
+}  // namespace
+
+}  // namespace eps

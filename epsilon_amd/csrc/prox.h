@@ -1,0 +1,109 @@
+// Proximal-operator plugin interface and registry.
+//
+// Same plugin point as the reference (src/epsilon/prox/prox.h:11-77): a ProxOperator is
+// created by (ProxFunction::Type, epigraph), initialised once with the function's affine
+// argument H and the constraint map A, then applied every sweep:
+//     Apply(v) = argmin_x f(H x + g) + 1/2 ||A x - v||^2 .
+// Operators register themselves with REGISTER_PROX_OPERATOR / REGISTER_EPIGRAPH_OPERATOR.
+#pragma once
+
+#include <functional>
+#include <memory>
+#include <string>
+
+#include "affine.h"
+#include "block.h"
+#include "wire.h"
+
+namespace eps {
+
+class ProxOperatorArg {  // reference prox/prox.h:11-35
+ public:
+  ProxOperatorArg(const pb::ProxFunction& f, DataMap* data, const AffineOperator& affine_arg,
+                  const AffineOperator& affine_constraint)
+      : f_(f), data_(data), H_(affine_arg), A_(affine_constraint) {}
+  const pb::ProxFunction& prox_function() const { return f_; }
+  DataMap* data_map() const { return data_; }
+  const AffineOperator& affine_arg() const { return H_; }
+  const AffineOperator& affine_constraint() const { return A_; }
+
+ private:
+  const pb::ProxFunction& f_;
+  DataMap* data_;
+  const AffineOperator& H_;
+  const AffineOperator& A_;
+};
+
+class ProxOperator {  // reference prox/prox.h:37-43
+ public:
+  virtual ~ProxOperator() {}
+  virtual void Init(const ProxOperatorArg& arg) {}
+  virtual BlockVector Apply(const BlockVector& v) = 0;
+};
+
+std::unique_ptr<ProxOperator> CreateProxOperator(int type, bool epigraph);
+bool RegisterProxOperatorFactory(int type, bool epigraph,
+                                 std::function<std::unique_ptr<ProxOperator>()> factory);
+
+template <class T> bool RegisterProxOperator(int type, bool epigraph) {
+  return RegisterProxOperatorFactory(type, epigraph,
+                                     [] { return std::unique_ptr<ProxOperator>(new T); });
+}
+
+#define EPS_REGISTER_VAR(prefix, type, T) prefix##_##type##_##T
+#define REGISTER_PROX_OPERATOR(type, T) \
+  static bool EPS_REGISTER_VAR(prox, type, T) = ::eps::RegisterProxOperator<T>(pb::ProxFunction::type, false)
+#define REGISTER_EPIGRAPH_OPERATOR(type, T) \
+  static bool EPS_REGISTER_VAR(epi, type, T) = ::eps::RegisterProxOperator<T>(pb::ProxFunction::type, true)
+
+// ---- VectorProx: prox with scalar / diagonal H and A reduced to a plain vector prox ------------
+// reference prox/vector_prox.{h,cc}
+
+class VectorProxInput {
+ public:
+  double lambda() const;                       // scalar case only
+  bool elementwise() const { return elementwise_; }
+  const DVec& lambda_vec() const { return lambda_dev_; }
+  const DVec& value_vec(int i) const;          // whole argument i (device)
+  const pb::ProxFunction& prox_function() const { return f_; }
+
+ private:
+  friend class VectorProx;
+  bool elementwise_ = false;
+  double lambda_ = 0;
+  std::vector<double> lambda_host_;
+  DVec lambda_dev_;
+  BlockVector v_;
+  pb::ProxFunction f_;
+};
+
+class VectorProxOutput {
+ public:
+  void set_value(int i, DVec x);
+
+ private:
+  friend class VectorProx;
+  BlockVector x_;
+};
+
+class VectorProx : public ProxOperator {
+ public:
+  void Init(const ProxOperatorArg& arg) override;
+  BlockVector Apply(const BlockVector& v) override;
+
+ protected:
+  // Applied to whole arguments.  When the function has an axis (per-row / per-column
+  // application, reference vector_prox.cc:150-177) the operator sees the full m x n argument
+  // and handles the axis itself; elementwise operators are axis-agnostic.
+  virtual void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) = 0;
+
+ private:
+  bool InitScalar(const ProxOperatorArg& arg);
+  bool InitDiagonal(const ProxOperatorArg& arg);
+  BlockMatrix B_, C_, D_;
+  BlockVector g_;
+  VectorProxInput input_;
+  VectorProxOutput output_;
+};
+
+}  // namespace eps

@@ -423,6 +423,7 @@ class SolverParams(Message):  # solver_params.proto:4-71 (fields the solver read
         Field("rel_tol", 13, "double", default=1e-2),
         Field("abs_tol", 14, "double", default=1e-4),
         Field("epoch_iterations", 18, "int", default=10),
+        Field("ignore_stopping_criteria", 24, "bool", default=False),
         Field("verbose", 27, "bool", default=False),
         Field("log_iterations", 28, "int", default=100),
         Field("use_epigraph", 29, "bool", default=True),

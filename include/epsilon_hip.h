@@ -1,0 +1,143 @@
+/* epsilon_hip.h - C ABI of the MI355X-native prox-ADMM solver core for Epsilon.
+ *
+ * This library replaces the solver side of Epsilon that sits behind the CPython extension
+ * `epopt._solve` (reference python/epopt/solvemodule.cc).  The payloads are the ones the
+ * unchanged frontend already produces:
+ *
+ *   problem / f_expr   protobuf wire bytes of `Problem` / `Expression`
+ *                      (reference proto/epsilon/expression.proto:205-346)
+ *   solver_params      protobuf wire bytes of `SolverParams` (proto/epsilon/solver_params.proto)
+ *   data               {location -> raw bytes}: dense = float64 column-major
+ *                      (reference python/epopt/constant.py:12-17)
+ *   variable values    float64, column-major, m*n per variable (solvemodule.cc:24-56,166-176)
+ *   status             protobuf wire bytes of `SolverStatus` (proto/epsilon/solver.proto:4-60)
+ *
+ * Every function returns 0 on success.  A non-zero return is what the reference reports as
+ * `_solve.error("CHECK failed")` (solvemodule.cc:158,185,245-248); the message is available
+ * from eps_last_error() (thread-local).  There is no CPU fallback: without a HIP device every
+ * compute entry point fails with an error.
+ *
+ * Not re-entrant per solver handle (the reference is not either: solvemodule.cc:17-22,
+ * prox/vector_prox.h:75-76); one process drives one GPU.
+ */
+#ifndef EPSILON_HIP_H_
+#define EPSILON_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One entry of the data map / of a variable-value map.
+ * Replaces: PyDict {str: str} walked by WriteConstants / GetVariableVector
+ * (reference solvemodule.cc:24-43,58-72). */
+enum {
+  EPS_BLOB_HOST = 0,       /* ptr -> host bytes, len = byte count (the reference's only form) */
+  EPS_BLOB_DEVICE_F32 = 1, /* ptr -> device memory, float,  len = element count (borrowed)   */
+  EPS_BLOB_DEVICE_F64 = 2  /* ptr -> device memory, double, len = element count (borrowed)   */
+};
+typedef struct eps_blob {
+  const char* key;  /* NUL-terminated location / variable id */
+  const void* ptr;  /* borrowed for the duration of the call (device blobs: of the solver) */
+  size_t len;
+  int kind;
+} eps_blob;
+
+/* A CVXPY Parameter binding: (parameter_id, serialized `Constant`).
+ * Replaces: the `parameters` iterable of `_solve.solve` (solvemodule.cc:89-106). */
+typedef struct eps_param {
+  const char* id;
+  const void* constant_proto;
+  size_t len;
+} eps_param;
+
+typedef struct eps_result eps_result; /* status bytes + {variable_id -> float64 bytes} */
+typedef struct eps_solver eps_solver; /* a live solver: operators, factorisation, iterates in HBM */
+
+/* ---- process-level ------------------------------------------------------------------------ */
+
+/* Message of the last failed call on this thread ("" if none). */
+const char* eps_last_error(void);
+/* "epsilon_hip <version> gfx950" */
+const char* eps_version(void);
+/* Options (all optional): "dtype" = "f32" (default) | "f64"  compute type of subsequent solves
+ * (env EPSILON_HIP_DTYPE);  "device" = ordinal, before first use (env EPSILON_HIP_DEVICE /
+ * LOCAL_RANK).  Rides outside SolverParams because the frontend passes only its own kwargs
+ * (reference python/epopt/cvxpy_solver.py:69). */
+int eps_set_option(const char* key, const char* value);
+/* Number of visible HIP devices (0 if none); never fails. */
+int eps_device_count(void);
+
+/* ---- the two entry points of `epopt._solve` ----------------------------------------------- */
+
+/* Replaces `_solve.solve(problem, parameters, solver_params, data)` (solvemodule.cc:110-187).
+ * On success *out holds the SolverStatus bytes and one float64 column-major vector per
+ * variable reachable from the problem, in lexicographic id order (solvemodule.cc:166). */
+int eps_solve(const void* problem, size_t problem_len, const void* solver_params,
+              size_t solver_params_len, const eps_blob* data, size_t ndata,
+              const eps_param* params, size_t nparams, eps_result** out);
+
+/* Replaces `_solve.eval_prox(f_expr, lam, data, v)` (solvemodule.cc:189-242):
+ * argmin_x lam*f(x) + 1/2||x - v||^2 for one PROX_FUNCTION expression.  `v` holds one
+ * float64 host blob per variable id.  The result has an empty status. */
+int eps_eval_prox(const void* f_expr, size_t f_expr_len, double lambda, const eps_blob* data,
+                  size_t ndata, const eps_blob* v, size_t nv, eps_result** out);
+
+/* Result accessors (pointers stay valid until eps_result_free). */
+int eps_result_status(const eps_result* r, const void** bytes, size_t* len);
+size_t eps_result_num_vars(const eps_result* r);
+int eps_result_var(const eps_result* r, size_t i, const char** id, const double** values,
+                   size_t* count);
+void eps_result_free(eps_result* r);
+
+/* ---- solver handles: warm start, staged runs, timing --------------------------------------- */
+/* Replaces the process-global warm-start cache (solvemodule.cc:22,142-156): the caller keeps the
+ * handle, so the data matrix, the cached factorisation and x/y/u stay resident in HBM across
+ * calls.  Host blobs are consumed during create/init; device blobs are borrowed until destroy. */
+int eps_solver_create(const void* problem, size_t problem_len, const void* solver_params,
+                      size_t solver_params_len, const eps_blob* data, size_t ndata,
+                      eps_solver** out);
+/* (Re)bind a CVXPY Parameter value; takes effect at the next eps_solver_init
+ * (reference algorithms/solver.cc:109-116). */
+int eps_solver_set_parameter(eps_solver* s, const char* id, const void* constant_proto,
+                             size_t len, const eps_blob* data, size_t ndata);
+/* Build operators / Gram matrix / factorisation (the reference's Solver::Init()).  With
+ * warm_start set in the params, x/y/u of a previous run are kept (prox_admm.cc:115-120). */
+int eps_solver_init(eps_solver* s);
+/* Run ADMM sweeps: until OPTIMAL / max_iterations if max_sweeps < 0, else at most max_sweeps
+ * more.  *sweeps_done may be NULL. */
+int eps_solver_run(eps_solver* s, int max_sweeps, int* sweeps_done);
+/* Snapshot of status + variables (same layout as eps_solve's result). */
+int eps_solver_result(eps_solver* s, eps_result** out);
+/* Wall-clock seconds spent in init and in the sweep loop (device-synchronised). */
+int eps_solver_timing(const eps_solver* s, double* init_seconds, double* loop_seconds);
+void eps_solver_destroy(eps_solver* s);
+
+/* ---- per-operator entry points (parity tests pin each kernel through these) ----------------- */
+
+/* y = op(A) x for a serialized `LinearMap` (reference linear/linear_map.cc:83-104 +
+ * LinearMapImpl::Apply); transpose != 0 applies the adjoint.  x, y: host float64. */
+int eps_linear_map_apply(const void* linear_map, size_t len, const eps_blob* data, size_t ndata,
+                         int transpose, const double* x, size_t nx, double* y, size_t ny);
+/* C = A op B with op = '+' or '*' through the type-dispatch tables (reference
+ * linear/linear_map_add.cc:234-284, linear_map_multiply.cc:249-299).  *result_type receives
+ * the ImplType of the result (0 dense, 1 sparse, 2 diagonal, 3 scalar, 4 kronecker);
+ * dense (m*n float64, column-major) receives its values; ta / tb transpose the operand first. */
+int eps_linear_map_binary(char op, const void* a, size_t a_len, int ta, const void* b,
+                          size_t b_len, int tb, const eps_blob* data, size_t ndata,
+                          int* result_type, int64_t* m, int64_t* n, double* dense,
+                          size_t dense_capacity);
+/* Inverse of a serialized map (reference LinearMapImpl::Inverse), dense values out. */
+int eps_linear_map_inverse(const void* linear_map, size_t len, const eps_blob* data,
+                           size_t ndata, double* dense, size_t dense_capacity);
+/* Exact 1-D total-variation prox of v (n float64) with weight lam
+ * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
+int eps_tv1d(const double* v, size_t n, double lam, double* x);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* EPSILON_HIP_H_ */

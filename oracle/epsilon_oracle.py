@@ -196,8 +196,11 @@ def lm_multiply(L, R):
     if a == SCALAR and b == KRONECKER:  # :188-198 stays Kronecker
         return LM.kron(lm_multiply(LM.scalar(L.alpha, R.KA.m), R.KA),
                        lm_multiply(LM.scalar(1.0, R.KB.m), R.KB))
-    if a == KRONECKER and b == SCALAR:  # :223-227 delegates with swapped args
-        return lm_multiply(R, L)
+    if a == KRONECKER and b == SCALAR:
+        # :223-227 calls the Scalar*Kron routine directly with swapped arguments: the scalar
+        # is re-sized from the Kronecker factors, so non-square Kronecker maps work too
+        return LM.kron(lm_multiply(LM.scalar(R.alpha, L.KA.m), L.KA),
+                       lm_multiply(LM.scalar(1.0, L.KB.m), L.KB))
     if a == KRONECKER and b == KRONECKER:  # :230-241
         if L.KA.n == R.KA.m and L.KB.n == R.KB.m:
             return LM.kron(lm_multiply(L.KA, R.KA), lm_multiply(L.KB, R.KB))

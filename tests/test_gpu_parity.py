@@ -1,0 +1,318 @@
+"""GPU parity tests: every case calls the HIP path through the C-ABI (epsilon_amd._solve ->
+libepsilon_hip.so) and checks it against the CPU oracle on the same seeded inputs.
+
+Tolerances: the GPU path runs in f64 (EPSILON dtype option) for tight parity with the fp64
+reference semantics, and in f32 (the production dtype, BASELINE.json north_star) within the
+stated fp32 tolerance.  Projection / threshold outputs are compared exactly where the
+operands are exactly representable.
+"""
+
+import numpy as np
+import pytest
+
+from epsilon_amd import ir, problems, wire
+from epsilon_amd.wire import ProxFunction
+from oracle import epsilon_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": dict(rtol=1e-10, atol=1e-11), "f32": dict(rtol=2e-4, atol=2e-5)}
+
+
+@pytest.fixture(params=["f64", "f32"])
+def dtype(request, solve_mod):
+    solve_mod.set_option("dtype", request.param)
+    yield request.param
+    solve_mod.set_option("dtype", "f32")
+
+
+def oracle_map(lmap):
+    return orc.build_linear_map(lmap.proto, lmap.data)
+
+
+def make_maps(rng):
+    return {
+        "dense": ir.dense_matrix(rng.randn(7, 5)),
+        "dense_t": ir.transpose(ir.dense_matrix(rng.randn(5, 7))),
+        "diag": ir.diagonal_matrix(rng.randn(6)),
+        "scalar": ir.scalar(-3.2, 6),
+        "kron_dd": ir.kronecker_product(ir.dense_matrix(rng.randn(2, 3)), ir.dense_matrix(rng.randn(4, 5))),
+        "kron_sd": ir.kronecker_product(ir.identity(3), ir.dense_matrix(rng.randn(4, 5))),
+        "kron_ds": ir.kronecker_product(ir.transpose(ir.dense_matrix(rng.randn(3, 2))), ir.scalar(2.5, 4)),
+        "big_dense": ir.dense_matrix(rng.randn(1030, 517)),
+        "odd_dense": ir.dense_matrix(rng.randn(333, 1201)),
+    }
+
+
+@pytest.mark.parametrize("name", ["dense", "dense_t", "diag", "scalar", "kron_dd", "kron_sd",
+                                  "kron_ds", "big_dense", "odd_dense"])
+def test_linear_map_apply_and_adjoint(solve_mod, dtype, name):
+    """reference linear/dense_matrix_impl_test.cc:24-29, kronecker_product_impl_test.cc:9-20."""
+    rng = np.random.RandomState(0)
+    A = make_maps(rng)[name]
+    O = oracle_map(A)
+    x = rng.randn(A.n)
+    y = rng.randn(A.m)
+    np.testing.assert_allclose(solve_mod.linear_map_apply(A, x), O.apply(x), **TOL[dtype])
+    np.testing.assert_allclose(solve_mod.linear_map_apply(A, y, transpose=True), O.T().apply(y),
+                               **TOL[dtype])
+
+
+def square_maps(rng, n=6):
+    return {
+        "dense": ir.dense_matrix(rng.randn(n, n)),
+        "diag": ir.diagonal_matrix(rng.randn(n)),
+        "scalar": ir.scalar(1.7, n),
+        "kron": ir.kronecker_product(ir.dense_matrix(rng.randn(2, 2)), ir.dense_matrix(rng.randn(3, 3))),
+        "kron_s": ir.kronecker_product(ir.dense_matrix(rng.randn(2, 2)), ir.scalar(0.5, 3)),
+    }
+
+
+@pytest.mark.parametrize("op", ["+", "*"])
+def test_linear_map_algebra_tables(solve_mod, dtype, op):
+    """All pairings of {Dense, Diagonal, Scalar, Kronecker}: values vs dense math and result
+    *type* vs the oracle's restatement of the dispatch tables
+    (reference linear/linear_map_test.cc:67-229)."""
+    rng = np.random.RandomState(1)
+    maps = square_maps(rng)
+    for an, A in maps.items():
+        for bn, B in maps.items():
+            OA, OB = oracle_map(A), oracle_map(B)
+            OC = orc.lm_add(OA, OB) if op == "+" else orc.lm_multiply(OA, OB)
+            rtype, dense = solve_mod.linear_map_binary(op, A, B)
+            np.testing.assert_allclose(dense, OC.as_dense(), err_msg="%s %s %s" % (an, op, bn),
+                                       **TOL[dtype])
+            expect = OC.type
+            if expect == orc.SPARSE:
+                expect = orc.DENSE  # sparse results are formed densely here (same fill count)
+            assert rtype == expect, "%s %s %s -> type %d, oracle %d" % (an, op, bn, rtype, expect)
+
+
+@pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 300])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_dense_inverse(solve_mod, dtype, n, sign):
+    """reference linear/dense_matrix_impl.cc:21-30 (LDLT explicit inverse); the KKT Schur
+    complements are +/- definite."""
+    rng = np.random.RandomState(n)
+    G = rng.randn(n, 2 * n + 3)
+    W = sign * (np.eye(n) + G.dot(G.T) / n)
+    inv = solve_mod.linear_map_inverse(ir.dense_matrix(W))
+    ref = np.linalg.inv(W)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(inv, ref, **tol)
+
+
+def test_gemm_mfma_vs_oracle(solve_mod):
+    """Dense*Dense through the f32 MFMA kernel (all four transpose combinations, ragged
+    edges) vs numpy."""
+    solve_mod.set_option("dtype", "f32")
+    rng = np.random.RandomState(2)
+    for (m, k, n) in [(300, 500, 260), (128, 64, 128), (129, 33, 65)]:
+        for ta in (False, True):
+            for tb in (False, True):
+                A = rng.randn(*((k, m) if ta else (m, k)))
+                B = rng.randn(*((n, k) if tb else (k, n)))
+                _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, tb)
+                ref = (A.T if ta else A).dot(B.T if tb else B)
+                np.testing.assert_allclose(C, ref, rtol=1e-4, atol=1e-3)
+    # SYRK path: A * A^T of one buffer
+    A = rng.randn(200, 700)
+    Am = ir.dense_matrix(A)
+    _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
+    np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-4, atol=1e-3)
+
+
+# ---- proximal operators through eval_prox -----------------------------------------------------------
+
+
+def run_prox(solve_mod, expr, lam, v_map, tol):
+    data = expr.data
+    fb = expr.proto.SerializeToString()
+    vb = {k: np.asarray(v, dtype=np.float64).tobytes(order="F") for k, v in v_map.items()}
+    got = solve_mod.eval_prox(fb, lam, data, vb)
+    want = orc.eval_prox(fb, lam, data, vb)
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_allclose(np.frombuffer(got[k]), np.frombuffer(want[k]), err_msg=k, **tol)
+    return got
+
+
+def prox_cases(rng, n=10):
+    x = ir.variable(n, 1, "var:x")
+    X = ir.variable(n, 3, "var:X")
+    w = rng.randn(n)
+    w[0] = 0
+    A20, b20 = rng.randn(20, n), rng.randn(20)
+    A5, b5 = rng.randn(5, n), rng.randn(5)
+    q_a = ir.constant(np.abs(rng.randn(n)))
+    q_b = ir.constant(np.abs(rng.randn(n)))
+    sz_q = wire.ProxScaledZoneParams(alpha_expr=q_a.proto, beta_expr=q_b.proto)
+    qdata = dict(q_a.data)
+    qdata.update(q_b.data)
+    cases = {
+        "norm_1": ir.prox(ProxFunction.NORM_1, x),
+        "norm_1_weighted": ir.prox(ProxFunction.NORM_1, ir.linear_map(ir.diagonal_matrix(w), x)),
+        "norm_1_scaled": ir.prox(ProxFunction.NORM_1, ir.linear_map(ir.scalar(-2.5, n), x), alpha=0.7),
+        "deadzone": ir.prox(ProxFunction.SUM_DEADZONE, x,
+                            scaled_zone_params=wire.ProxScaledZoneParams(m=0.4)),
+        "hinge": ir.prox(ProxFunction.SUM_HINGE, x),
+        "hinge_1mx": ir.prox(ProxFunction.SUM_HINGE,
+                             ir.add(ir.linear_map(ir.scalar(-1, n), x), ir.scalar_constant(1.0, (n, 1)))),
+        "quantile": ir.prox(ProxFunction.SUM_QUANTILE, x, scaled_zone_params=sz_q, data=qdata),
+        "norm_2": ir.prox(ProxFunction.NORM_2, x),
+        "norm_2_fro": ir.prox(ProxFunction.NORM_2, ir.reshape(X, 3 * n, 1), arg_size=[(3 * n, 1)]),
+        "non_negative": ir.prox(ProxFunction.NON_NEGATIVE, x),
+        "non_negative_scaled": ir.prox(ProxFunction.NON_NEGATIVE, ir.linear_map(ir.scalar(-1.3, n), x)),
+        "non_negative_elemwise": ir.prox(ProxFunction.NON_NEGATIVE,
+                                         ir.linear_map(ir.diagonal_matrix(rng.randn(n)), x)),
+        "sum_square_20": ir.prox(ProxFunction.SUM_SQUARE,
+                                 ir.add(ir.linear_map(ir.dense_matrix(A20), x),
+                                        ir.linear_map(ir.scalar(-1, 20), ir.constant(b20)))),
+        "sum_square_5": ir.prox(ProxFunction.SUM_SQUARE,
+                                ir.add(ir.linear_map(ir.dense_matrix(A5), x),
+                                       ir.linear_map(ir.scalar(-1, 5), ir.constant(b5)))),
+        "sum_square_matrix": ir.prox(ProxFunction.SUM_SQUARE,
+                                     ir.add(ir.linear_map(ir.left_matrix_product(ir.dense_matrix(A20), 3),
+                                                          ir.reshape(X, 3 * n, 1)),
+                                            ir.linear_map(ir.scalar(-1, 60), ir.constant(rng.randn(60))))),
+        "zero": ir.prox(ProxFunction.ZERO,
+                        ir.add(ir.linear_map(ir.dense_matrix(A5), x),
+                               ir.linear_map(ir.scalar(-1, 5), ir.constant(A5.dot(rng.randn(n)))))),
+        "affine": ir.prox(ProxFunction.AFFINE, ir.linear_map(ir.dense_matrix(rng.randn(1, n)), x)),
+        "tv_1d": ir.prox(ProxFunction.TOTAL_VARIATION_1D, x),
+    }
+    return cases
+
+
+PROX_NAMES = ["norm_1", "norm_1_weighted", "norm_1_scaled", "deadzone", "hinge", "hinge_1mx",
+              "quantile", "norm_2", "norm_2_fro", "non_negative", "non_negative_scaled",
+              "non_negative_elemwise", "sum_square_20", "sum_square_5", "sum_square_matrix",
+              "zero", "affine", "tv_1d"]
+
+
+@pytest.mark.parametrize("name", PROX_NAMES)
+def test_eval_prox_vs_oracle(solve_mod, dtype, name):
+    """The prox cases of reference python/epopt/prox_test.py:168-221 that this build covers,
+    3 seeded trials each, random lambda as prox_test.py:279-283."""
+    for trial in range(3):
+        rng = np.random.RandomState(trial)
+        expr = prox_cases(rng)[name]
+        lam = abs(rng.randn()) + 0.05
+        v_map = {vid: rng.randn(sz[0] * sz[1]) for vid, sz in ir.get_variables(expr.proto).items()}
+        tol = TOL[dtype] if dtype == "f64" else dict(rtol=5e-4, atol=5e-5)
+        run_prox(solve_mod, expr, lam, v_map, tol)
+
+
+def test_projections_are_bit_exact(solve_mod):
+    """max(v,0) and the dead-zone / threshold branches on f32-representable inputs must match
+    the oracle bit for bit (north_star: bit-exact for indexing/projection ops)."""
+    solve_mod.set_option("dtype", "f32")
+    rng = np.random.RandomState(3)
+    n = 4099
+    v = rng.randn(n).astype(np.float32).astype(np.float64)
+    x = ir.variable(n, 1, "var:x")
+    got = run_prox(solve_mod, ir.prox(ProxFunction.NON_NEGATIVE, x), 1.0, {"var:x": v},
+                   dict(rtol=0, atol=0))
+    assert np.array_equal(np.frombuffer(got["var:x"]), np.maximum(v, 0))
+    # soft threshold with lam = 1 (all scalings are exactly 1): the f32 result is exact
+    got = run_prox(solve_mod, ir.prox(ProxFunction.NORM_1, x), 1.0, {"var:x": v}, dict(rtol=0, atol=0))
+    v32 = v.astype(np.float32)
+    ref = (np.sign(v32) * np.maximum(np.abs(v32) - np.float32(1), np.float32(0))).astype(np.float64)
+    assert np.array_equal(np.frombuffer(got["var:x"]), ref)
+
+
+# ---- ADMM drivers -------------------------------------------------------------------------------------
+
+
+def solve_both(solve_mod, prob, params):
+    pb, sb, data = prob.SerializeToString(), params.SerializeToString(), prob.expression_data()
+    st_g, x_g = solve_mod.solve(pb, [], sb, data)
+    st_o, x_o = orc.solve(pb, [], sb, data)
+    return wire.SolverStatus.FromString(st_g), x_g, wire.SolverStatus.FromString(st_o), x_o
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("shape", [(200, 500), (40, 15)])
+def test_lasso_iterates_match_oracle(solve_mod, dtype, solver, shape):
+    """BASELINE.json configs[0]: lasso 200x500 (fat: eliminates to the m x m Gram A A^T) and a
+    tall 40x15 instance (the other elimination order, n x n Gram), both drivers."""
+    prob, info = problems.lasso(shape[0], shape[1], seed=0)
+    params = wire.SolverParams(solver=solver)
+    sg, xg, so, xo = solve_both(solve_mod, prob, params)
+    assert sg.state == so.state == wire.SolverStatus.OPTIMAL
+    assert sg.num_iterations == so.num_iterations
+    rt = 1e-8 if dtype == "f64" else 2e-3
+    for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
+        np.testing.assert_allclose(getattr(sg.residuals, f), getattr(so.residuals, f), rtol=rt, atol=1e-9 if dtype == "f64" else 1e-5)
+    tol = dict(rtol=1e-8, atol=1e-10) if dtype == "f64" else dict(rtol=1e-3, atol=1e-4)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
+
+
+def test_lasso_fixed_sweeps_trace(solve_mod, dtype):
+    """Iterate parity sweep by sweep: run exactly k sweeps on the GPU (solver handle) and in
+    the oracle and compare x after sweeps 1, 2, 3, 10."""
+    prob, info = problems.lasso(60, 150, seed=1)
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    for k in (1, 2, 3, 10):
+        params = wire.SolverParams(max_iterations=k)
+        sb = params.SerializeToString()
+        sg, xg, so, xo = solve_both(solve_mod, prob, params)
+        assert sg.num_iterations == so.num_iterations == k
+        tol = dict(rtol=1e-9, atol=1e-11) if dtype == "f64" else dict(rtol=1e-3, atol=1e-4)
+        for key in xo:
+            np.testing.assert_allclose(np.frombuffer(xg[key]), np.frombuffer(xo[key]), **tol)
+
+
+def test_solver_handle_staged_run_equals_one_shot(solve_mod, dtype):
+    prob, info = problems.lasso(50, 120, seed=2)
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    sb = wire.SolverParams().SerializeToString()
+    st1, x1 = solve_mod.solve(pb, [], sb, data)
+    s = solve_mod.Solver(pb, sb, data)
+    s.init()
+    total = 0
+    while True:
+        done = s.run(7)
+        total += done
+        if done < 7:
+            break
+    st2, x2 = s.result()
+    s.close()
+    a, b = wire.SolverStatus.FromString(st1), wire.SolverStatus.FromString(st2)
+    assert a.state == b.state and a.num_iterations == b.num_iterations
+    for k in x1:
+        assert np.array_equal(np.frombuffer(x1[k]), np.frombuffer(x2[k]))
+
+
+def test_tv_1d_problem(solve_mod, dtype):
+    prob, info = problems.tv_1d(200, seed=0)
+    sg, xg, so, xo = solve_both(solve_mod, prob, wire.SolverParams())
+    assert sg.state == so.state
+    assert sg.num_iterations == so.num_iterations
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == "f64" else dict(rtol=2e-3, atol=2e-3)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), **tol)
+
+
+def test_multiclass_hinge_problem(solve_mod, dtype):
+    """Kronecker constraint maps + AFFINE / NON_NEGATIVE / SUM_SQUARE terms (config 4 shape)."""
+    X, Y = problems.multiclass_hinge_data(30, 8, 3, seed=0)
+    prob, info = problems.multiclass_hinge(X, Y, lam=0.1)
+    params = wire.SolverParams(max_iterations=40)
+    sg, xg, so, xo = solve_both(solve_mod, prob, params)
+    assert sg.num_iterations == so.num_iterations
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == "f64" else dict(rtol=5e-3, atol=5e-3)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
+
+
+def test_error_reporting(solve_mod):
+    """A failed CHECK surfaces as _solve.error with a message (reference: longjmp ->
+    _solve.error("CHECK failed"), solvemodule.cc:245-248)."""
+    with pytest.raises(solve_mod.error):
+        solve_mod.solve(b"\x0a\x02\x08\x0a", [], b"", {})  # objective ADD with no terms / no data
+    x = ir.variable(5, 1, "var:x")
+    bad = ir.prox(ProxFunction.NORM_NUCLEAR + 2, x)  # SIGMA_MAX: no operator registered
+    with pytest.raises(solve_mod.error):
+        solve_mod.eval_prox(bad.proto.SerializeToString(), 1.0, {}, {"var:x": np.zeros(5).tobytes()})
