@@ -208,6 +208,25 @@ class Solver(object):
             pass
 
 
+def profile_enable(on=True):
+    _check(lib().eps_profile_enable(ctypes.c_int(1 if on else 0)))
+
+
+def profile_reset():
+    _check(lib().eps_profile_reset())
+
+
+def profile_dump():
+    """{tag: (count, total_ms)} of the live HIP-event kernel timers."""
+    buf = ctypes.create_string_buffer(1 << 16)
+    _check(lib().eps_profile_dump(buf, ctypes.c_size_t(len(buf))))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        tag, count, ms = line.rsplit(" ", 2)
+        out[tag] = (int(count), float(ms))
+    return out
+
+
 # ---- per-operator entry points ------------------------------------------------------------------
 
 

@@ -267,6 +267,31 @@ void eps_solver_destroy(eps_solver* s) {
   }
 }
 
+int eps_profile_enable(int on) {
+  return Guard([&] { Runtime::Get().set_profiling(on != 0); });
+}
+
+int eps_profile_reset(void) {
+  return Guard([&] { Runtime::Get().ProfReset(); });
+}
+
+int eps_profile_dump(char* buf, size_t cap) {
+  return Guard([&] {
+    EPS_CHECK(buf != nullptr && cap > 0);
+    Runtime& rt = Runtime::Get();
+    rt.ProfCollect();
+    std::string out;
+    for (const auto& kv : rt.prof_totals()) {
+      char line[256];
+      std::snprintf(line, sizeof(line), "%s %lld %.6f\n", kv.first.c_str(),
+                    static_cast<long long>(kv.second.count), kv.second.ms);
+      out += line;
+    }
+    std::strncpy(buf, out.c_str(), cap - 1);
+    buf[cap - 1] = 0;
+  });
+}
+
 int eps_linear_map_apply(const void* linear_map, size_t len, const eps_blob* data, size_t ndata,
                          int transpose, const double* x, size_t nx, double* y, size_t ny) {
   return Guard([&] {

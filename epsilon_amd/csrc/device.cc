@@ -105,6 +105,60 @@ void Runtime::FetchSlots() {
 
 void Runtime::Sync() { EPS_HIP(hipStreamSynchronize(stream_)); }
 
+void Runtime::ProfBegin(const std::string& tag) {
+  ProfPending e;
+  e.tag = tag;
+  for (hipEvent_t* ev : {&e.a, &e.b}) {
+    if (!prof_free_.empty()) {
+      *ev = prof_free_.back();
+      prof_free_.pop_back();
+    } else {
+      EPS_HIP(hipEventCreate(ev));
+    }
+  }
+  EPS_HIP(hipEventRecord(e.a, stream_));
+  prof_pending_.push_back(e);
+}
+
+void Runtime::ProfEnd() {
+  EPS_HIP(hipEventRecord(prof_pending_.back().b, stream_));
+  if (prof_pending_.size() >= 8192) ProfCollect();
+}
+
+void Runtime::ProfCollect() {
+  if (prof_pending_.empty()) return;
+  EPS_HIP(hipStreamSynchronize(stream_));
+  for (auto& e : prof_pending_) {
+    float ms = 0;
+    EPS_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+    ProfTotal& t = prof_totals_[e.tag];
+    t.count += 1;
+    t.ms += ms;
+    prof_free_.push_back(e.a);
+    prof_free_.push_back(e.b);
+  }
+  prof_pending_.clear();
+}
+
+void Runtime::ProfReset() {
+  ProfCollect();
+  prof_totals_.clear();
+}
+
+ProfScope::ProfScope(const char* name, int64_t a, int64_t b) {
+  Runtime& rt = Runtime::Get();
+  on = rt.profiling();
+  if (!on) return;
+  std::string tag = name;
+  if (a >= 0) tag += ":" + std::to_string(a);
+  if (b >= 0) tag += "x" + std::to_string(b);
+  rt.ProfBegin(tag);
+}
+
+ProfScope::~ProfScope() {
+  if (on) Runtime::Get().ProfEnd();
+}
+
 static thread_local DType g_current_dtype = F32;
 DType CurrentDType() { return g_current_dtype; }
 void SetCurrentDType(DType dt) { g_current_dtype = dt; }

@@ -57,6 +57,16 @@ class Runtime {
 
   void Sync();
 
+  // ---- live kernel timing (HIP events on this stream; off unless eps_profile_enable) -------
+  bool profiling() const { return profiling_; }
+  void set_profiling(bool on) { profiling_ = on; }
+  void ProfBegin(const std::string& tag);
+  void ProfEnd();
+  void ProfCollect();  // synchronises, folds finished event pairs into the totals
+  void ProfReset();
+  struct ProfTotal { int64_t count = 0; double ms = 0; };
+  const std::map<std::string, ProfTotal>& prof_totals() const { return prof_totals_; }
+
   Comm* comm() { return comm_; }
   void set_comm(Comm* c) { comm_ = c; }
 
@@ -75,6 +85,18 @@ class Runtime {
   double* slots_host_ = nullptr;
   int slots_used_ = 0;
   Comm* comm_ = nullptr;
+  bool profiling_ = false;
+  struct ProfPending { std::string tag; hipEvent_t a, b; };
+  std::vector<ProfPending> prof_pending_;
+  std::vector<hipEvent_t> prof_free_;
+  std::map<std::string, ProfTotal> prof_totals_;
+};
+
+// RAII scope around one kernel launch (or a short launch sequence) for live timing.
+struct ProfScope {
+  bool on;
+  explicit ProfScope(const char* name, int64_t a = -1, int64_t b = -1);
+  ~ProfScope();
 };
 
 // Compute dtype of the solve being set up on this thread (f32 unless EPSILON_HIP_DTYPE=f64 or

@@ -102,6 +102,7 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
   if (n == 0) return;
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
+  ProfScope prof("spd_inverse", n);
   const DType dt = W.dt;
   const int64_t ld = n;
   const int64_t nb = (n + NB - 1) / NB;

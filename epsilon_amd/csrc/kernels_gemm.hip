@@ -230,6 +230,7 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
   EPS_CHECK_MSG(C.n >= (N - 1) * ldc + M, "gemm: C buffer too small");
   if (lower_only) EPS_CHECK(M == N);
   hipStream_t s = Runtime::Get().stream();
+  ProfScope prof(lower_only ? "syrk" : "gemm", M * N, K);
   const int mode = GemmMode();
   const bool use_mfma = A.dt == F32 && mode != 1 &&
                         (mode == 2 || (M >= 64 && N >= 64 && K >= 32));

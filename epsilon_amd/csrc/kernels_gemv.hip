@@ -273,6 +273,7 @@ void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, i
     else Axpby(y, beta, y, 0.0);  // y = beta*y
     return;
   }
+  ProfScope prof(trans ? "gemv_t" : "gemv_n", rows, cols);
   if (A.dt == F32) {
     if (trans) LaunchGemvT<float>(rows, cols, alpha, A.as<float>(), lda, x.as<float>(), beta, y.as<float>());
     else LaunchGemvN<float>(rows, cols, alpha, A.as<float>(), lda, x.as<float>(), beta, y.as<float>());

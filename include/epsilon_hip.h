@@ -115,6 +115,14 @@ int eps_solver_result(eps_solver* s, eps_result** out);
 int eps_solver_timing(const eps_solver* s, double* init_seconds, double* loop_seconds);
 void eps_solver_destroy(eps_solver* s);
 
+/* ---- live kernel timing ---------------------------------------------------------------------- */
+/* When enabled, every hot kernel launch is bracketed by HIP events on the solver's stream.
+ * eps_profile_dump writes one line per tag "tag count total_ms\n" (NUL-terminated, truncated
+ * to cap) after synchronising; eps_profile_reset clears the totals. */
+int eps_profile_enable(int on);
+int eps_profile_reset(void);
+int eps_profile_dump(char* buf, size_t cap);
+
 /* ---- per-operator entry points (parity tests pin each kernel through these) ----------------- */
 
 /* y = op(A) x for a serialized `LinearMap` (reference linear/linear_map.cc:83-104 +

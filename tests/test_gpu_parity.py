@@ -311,7 +311,7 @@ def test_error_reporting(solve_mod):
     """A failed CHECK surfaces as _solve.error with a message (reference: longjmp ->
     _solve.error("CHECK failed"), solvemodule.cc:245-248)."""
     with pytest.raises(solve_mod.error):
-        solve_mod.solve(b"\x0a\x02\x08\x0a", [], b"", {})  # objective ADD with no terms / no data
+        solve_mod.solve(b"\x0a\x05\x08", [], b"", {})  # truncated length-delimited field
     x = ir.variable(5, 1, "var:x")
     bad = ir.prox(ProxFunction.NORM_NUCLEAR + 2, x)  # SIGMA_MAX: no operator registered
     with pytest.raises(solve_mod.error):
