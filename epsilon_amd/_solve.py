@@ -208,6 +208,45 @@ class Solver(object):
             pass
 
 
+# ---- sharded solves ---------------------------------------------------------------------------------
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                ctypes.c_void_p)
+_comm_keep = []
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    _check(lib().eps_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init_rccl(rank, world, unique_id):
+    _check(lib().eps_comm_init_rccl(ctypes.c_int(rank), ctypes.c_int(world), unique_id))
+
+
+def comm_init_callback(rank, world, fn):
+    """fn(numpy_array) must sum the array in place across ranks."""
+    def trampoline(ptr, count, dtype, ctx):
+        ctype = ctypes.c_float if dtype == 0 else ctypes.c_double
+        arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctype)), shape=(count,))
+        fn(arr)
+    cb = ALLREDUCE_FN(trampoline)
+    _comm_keep.append(cb)
+    _check(lib().eps_comm_init_callback(ctypes.c_int(rank), ctypes.c_int(world), cb, None))
+
+
+def comm_shutdown():
+    _check(lib().eps_comm_shutdown())
+    del _comm_keep[:]
+
+
+def shard_keys(keys):
+    keys = [k.encode("utf-8") for k in keys]
+    arr = (ctypes.c_char_p * max(len(keys), 1))(*keys)
+    _check(lib().eps_shard_keys(arr, ctypes.c_size_t(len(keys))))
+
+
 def profile_enable(on=True):
     _check(lib().eps_profile_enable(ctypes.c_int(1 if on else 0)))
 

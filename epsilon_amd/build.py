@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libepsilon_hip.so")
 
-HOST_SOURCES = ["wire.cc", "device.cc", "linear_map.cc", "block.cc", "affine.cc", "prox.cc",
+HOST_SOURCES = ["wire.cc", "device.cc", "comm.cc", "linear_map.cc", "block.cc", "affine.cc", "prox.cc",
                 "admm.cc", "capi.cc"]
 # -ffp-contract=off for the elementwise / prox kernels: thresholds and projections must pick
 # the same branch and produce the same bits as a plain IEEE evaluation.
@@ -70,7 +70,7 @@ def build(verbose=False, jobs=None):
                 sys.stderr.write(warn)
     objs = [w[1] for w in work]
     if _newer(objs[0], LIB, objs[1:]):
-        cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        cmd = [hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr)

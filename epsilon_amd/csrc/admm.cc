@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 
+#include "comm.h"
 #include "kernels.h"
 
 namespace eps {
@@ -13,6 +14,54 @@ namespace {
 double Now() {
   using clock = std::chrono::steady_clock;
   return std::chrono::duration<double>(clock::now().time_since_epoch()).count();
+}
+
+// Sharded solves: the "arg:<k>" rows of a prox operator's H are private to that operator.  An
+// arg row fed from a sharded variable through an elementwise map is itself sharded; through a
+// dense / Kronecker map it is a contraction into a replicated row (comm.h).
+std::set<std::string> InferShardedArgs(const BlockMatrix& H) {
+  std::set<std::string> out;
+  const ShardSpec& sh = ShardSpec::Get();
+  if (!sh.active()) return out;
+  std::map<std::string, int> vote;  // 1 sharded, 2 replicated
+  for (const auto& col : H.data()) {
+    if (!sh.IsSharded(col.first)) continue;
+    for (const auto& row : col.second) {
+      const ImplType t = row.second.impl().type();
+      const int v = (t == SCALAR_MATRIX || t == DIAGONAL_MATRIX) ? 1 : 2;
+      int& cur = vote[row.first];
+      EPS_CHECK_MSG(cur == 0 || cur == v, "row " << row.first
+                                                  << " mixes elementwise and dense maps of sharded variables");
+      cur = v;
+    }
+  }
+  for (const auto& kv : vote)
+    if (kv.second == 1) out.insert(kv.first);
+  return out;
+}
+
+// Global row / column counts of a block matrix whose sharded keys hold per-rank slices.
+void GlobalDims(const BlockMatrix& A, int64_t* m, int64_t* n) {
+  const ShardSpec& sh = ShardSpec::Get();
+  if (!sh.active()) {
+    *m = A.m();
+    *n = A.n();
+    return;
+  }
+  double loc[2] = {0, 0}, rep[2] = {0, 0};
+  std::set<std::string> seen;
+  for (const auto& col : A.data()) {
+    const int64_t cn = col.second.begin()->second.impl().n();
+    (sh.IsSharded(col.first) ? loc : rep)[1] += cn;
+    for (const auto& row : col.second)
+      if (seen.insert(row.first).second)
+        (sh.IsSharded(row.first) ? loc : rep)[0] += row.second.impl().m();
+  }
+  DVec d = DVec::FromHost(loc, 2, F64);
+  Runtime::Get().comm()->AllReduceSum(d);
+  std::vector<double> g = d.ToHost();
+  *m = static_cast<int64_t>(g[0] + rep[0] + 0.5);
+  *n = static_cast<int64_t>(g[1] + rep[1] + 0.5);
 }
 
 }  // namespace
@@ -129,8 +178,7 @@ class ProxADMMSolver final : public Solver {
       affine::BuildAffineOperator(constr.arg[0], data_.get(), affine::constraint_key(i), &A_, &b_);
     }
     AT_ = A_.Transpose();
-    m_ = A_.m();
-    n_ = A_.n();
+    GlobalDims(A_, &m_, &n_);
   }
 
   void InitProxOperators() {  // :45-94
@@ -140,6 +188,7 @@ class ProxADMMSolver final : public Solver {
     const double sqrt_rho = std::sqrt(params_.rho);
     prox_.clear();
     AiT_.clear();
+    arg_shards_.clear();
     std::set<std::string> constr_vars = A_.col_keys();
     for (int i = 0; i < N_; ++i) {
       const pb::Expression& f_expr = problem_.objective.arg[i];
@@ -157,7 +206,11 @@ class ProxADMMSolver final : public Solver {
       }
       prox_.emplace_back(CreateProxOperator(f_expr.prox_function.prox_function_type,
                                             f_expr.prox_function.epigraph));
-      prox_.back()->Init(ProxOperatorArg(f_expr.prox_function, data_.get(), H, A));
+      arg_shards_.push_back(InferShardedArgs(H.A));
+      {
+        LocalShardScope scope(arg_shards_.back());
+        prox_.back()->Init(ProxOperatorArg(f_expr.prox_function, data_.get(), H, A));
+      }
       AiT_.push_back(A.A.Transpose());
     }
   }
@@ -178,7 +231,10 @@ class ProxADMMSolver final : public Solver {
     for (int i = 0; i < N_; ++i) u_ -= y_[i];
     for (int i = 0; i < N_; ++i) {
       u_ += y_[i];
-      x_[i] = prox_[i]->Apply(u_);
+      {
+        LocalShardScope scope(arg_shards_[i]);
+        x_[i] = prox_[i]->Apply(u_);
+      }
       y_[i] = A_ * x_[i];
       u_ -= y_[i];
     }
@@ -227,6 +283,7 @@ class ProxADMMSolver final : public Solver {
   BlockVector b_;
   std::vector<BlockMatrix> AiT_;
   std::vector<std::unique_ptr<ProxOperator>> prox_;
+  std::vector<std::set<std::string>> arg_shards_;
   BlockVector u_;
   std::vector<BlockVector> x_, y_, y_prev_;
 };
@@ -263,12 +320,12 @@ class ProxADMMTwoBlockSolver final : public Solver {
     constr_prox_ = CreateProxOperator(pb::ProxFunction::ZERO, false);
     zero_f_ = pb::ProxFunction();
     constr_prox_->Init(ProxOperatorArg(zero_f_, data_.get(), H, A));
-    m_ = H.A.m();
-    n_ = H.A.n();
+    GlobalDims(H.A, &m_, &n_);
 
     EPS_CHECK_MSG(problem_.objective.expression_type == pb::Expression::ADD, "objective is not ADD");
     N_ = static_cast<int>(problem_.objective.arg.size());
     prox_.clear();
+    arg_shards_.clear();
     for (int i = 0; i < N_; ++i) {
       const pb::Expression& f_expr = problem_.objective.arg[i];
       EPS_CHECK_MSG(f_expr.expression_type == pb::Expression::PROX_FUNCTION,
@@ -282,6 +339,8 @@ class ProxADMMTwoBlockSolver final : public Solver {
         Ai.A(var.first, var.first) = sqrt_rho * LinearMap::Identity(GetDimension(*var.second));
       prox_.emplace_back(CreateProxOperator(f_expr.prox_function.prox_function_type,
                                             f_expr.prox_function.epigraph));
+      arg_shards_.push_back(InferShardedArgs(Hi.A));
+      LocalShardScope scope(arg_shards_.back());
       prox_.back()->Init(ProxOperatorArg(f_expr.prox_function, data_.get(), Hi, Ai));
     }
     if (!params_.warm_start || !vars_initialized_) {
@@ -305,7 +364,10 @@ class ProxADMMTwoBlockSolver final : public Solver {
     z_prev_ = z_;
     BlockVector zu = z_ - u_;
     x_ = BlockVector();
-    for (int i = 0; i < N_; ++i) x_ += prox_[i]->Apply(zu);
+    for (int i = 0; i < N_; ++i) {
+      LocalShardScope scope(arg_shards_[i]);
+      x_ += prox_[i]->Apply(zu);
+    }
     z_ = constr_prox_->Apply(x_ + u_);
     u_ += x_ - z_;
   }
@@ -333,6 +395,7 @@ class ProxADMMTwoBlockSolver final : public Solver {
   bool vars_initialized_ = false;
   pb::ProxFunction zero_f_;
   std::vector<std::unique_ptr<ProxOperator>> prox_;
+  std::vector<std::set<std::string>> arg_shards_;
   std::unique_ptr<ProxOperator> constr_prox_;
   BlockVector x_, z_, u_, z_prev_;
 };

@@ -5,6 +5,7 @@
 #include <sstream>
 #include <unordered_set>
 
+#include "comm.h"
 #include "kernels.h"
 
 namespace eps {
@@ -96,17 +97,21 @@ BlockVector BlockVector::Select(const std::set<std::string>& keys) const {
   return r;
 }
 
+namespace {
+inline double* SlotFor(Runtime& rt, int s, const std::string& key) {
+  const ShardSpec& sh = ShardSpec::Get();
+  return (sh.active() && sh.IsSharded(key)) ? rt.ShardSlotPtr(s) : rt.SlotPtr(s);
+}
+}  // namespace
+
 int BlockVector::NormSqAsync() const {
+  // slots are zeroed by ResetSlots; sharded blocks add into the slot's sharded half, which
+  // FetchSlots all-reduces
   Runtime& rt = Runtime::Get();
   int s = rt.NewSlot();
-  bool first = true;
   for (const auto& kv : data_) {
     if (kv.second.n == 0) continue;
-    k::SumSq(kv.second, rt.SlotPtr(s), !first);
-    first = false;
-  }
-  if (first) {
-    EPS_HIP(hipMemsetAsync(rt.SlotPtr(s), 0, sizeof(double), rt.stream()));
+    k::SumSq(kv.second, SlotFor(rt, s, kv.first), true);
   }
   return s;
 }
@@ -122,21 +127,19 @@ double BlockVector::norm() const {
 int DiffNormSqAsync(const BlockVector& a, const BlockVector& b) {
   Runtime& rt = Runtime::Get();
   int s = rt.NewSlot();
-  bool first = true;
   std::set<std::string> keys = a.keys();
   for (const auto& key : b.keys()) keys.insert(key);
   for (const auto& key : keys) {
+    double* slot = SlotFor(rt, s, key);
     if (a.has_key(key) && b.has_key(key)) {
       if (a(key).n == 0) continue;
-      k::SumSqDiff(a(key), b(key), rt.SlotPtr(s), !first);
+      k::SumSqDiff(a(key), b(key), slot, true);
     } else {
       const DVec& v = a.has_key(key) ? a(key) : b(key);
       if (v.n == 0) continue;
-      k::SumSq(v, rt.SlotPtr(s), !first);
+      k::SumSq(v, slot, true);
     }
-    first = false;
   }
-  if (first) EPS_HIP(hipMemsetAsync(rt.SlotPtr(s), 0, sizeof(double), rt.stream()));
   return s;
 }
 
@@ -216,7 +219,22 @@ BlockMatrix operator*(const BlockMatrix& A, const BlockMatrix& B) {  // block_ma
     for (const auto& b : bcol.second) {
       auto acol = A.data_.find(b.first);
       if (acol == A.data_.end()) continue;
-      for (const auto& a : acol->second) C.InsertOrAdd(a.first, bcol.first, a.second * b.second);
+      for (const auto& a : acol->second) {
+        LinearMap P = a.second * b.second;
+        // contraction over a sharded key into a replicated block: partial product, sum it
+        const ShardSpec& sh = ShardSpec::Get();
+        if (sh.active() && sh.IsSharded(b.first) && !sh.IsSharded(a.first) &&
+            !sh.IsSharded(bcol.first)) {
+          EPS_CHECK_MSG(P.impl().type() == DENSE_MATRIX,
+                        "sharded contraction (" << a.first << "," << b.first << ")*(" << b.first
+                                                << "," << bcol.first << ") must be dense");
+          const auto& D = static_cast<const DenseMatrixImpl&>(P.impl());
+          DVec buf = D.Materialize(true);
+          Runtime::Get().comm()->AllReduceSum(buf);
+          P = LinearMap::Dense(buf, D.m(), D.n());
+        }
+        C.InsertOrAdd(a.first, bcol.first, P);
+      }
     }
   }
   return C;
@@ -239,11 +257,35 @@ BlockMatrix operator*(double alpha, const BlockMatrix& A) {
 }
 
 BlockVector operator*(const BlockMatrix& A, const BlockVector& x) {  // block_matrix.cc:155-168
-  BlockVector y;
+  const ShardSpec& sh = ShardSpec::Get();
+  if (!sh.active()) {
+    BlockVector y;
+    for (const auto& xk : x.data()) {
+      auto col = A.data_.find(xk.first);
+      if (col == A.data_.end()) continue;
+      for (const auto& blk : col->second)
+        y.InsertOrAddApply(blk.first, blk.second.impl(), xk.second);
+    }
+    return y;
+  }
+  // Sharded solve: contributions of sharded columns to replicated rows are partial sums over
+  // this rank's slice.  Gather them apart, all-reduce once per such row, then add the rest.
+  BlockVector y, partial;
   for (const auto& xk : x.data()) {
     auto col = A.data_.find(xk.first);
     if (col == A.data_.end()) continue;
-    for (const auto& blk : col->second) y.InsertOrAddApply(blk.first, blk.second.impl(), xk.second);
+    const bool src_sharded = sh.IsSharded(xk.first);
+    for (const auto& blk : col->second) {
+      if (src_sharded && !sh.IsSharded(blk.first))
+        partial.InsertOrAddApply(blk.first, blk.second.impl(), xk.second);
+      else
+        y.InsertOrAddApply(blk.first, blk.second.impl(), xk.second);
+    }
+  }
+  for (const auto& kv : partial.data()) {
+    DVec p = partial.Mutable(kv.first);
+    Runtime::Get().comm()->AllReduceSum(p);
+    y.InsertOrAdd(kv.first, p);
   }
   return y;
 }
@@ -308,6 +350,7 @@ void BlockMatrix::Remove(const std::string& row, const std::string& col) {
 // ---- BlockCholesky (reference vector/block_cholesky.cc) ---------------------------------------------
 
 static const uint64_t kFillMax = std::numeric_limits<uint64_t>::max();
+static const uint64_t kFillForbidden = kFillMax - 1;  // sharded solve: would couple ranks
 
 uint64_t ComputeFill(const BlockMatrix& A, const std::string& k) {  // :11-48
   std::set<std::string> keys;
@@ -317,11 +360,19 @@ uint64_t ComputeFill(const BlockMatrix& A, const std::string& k) {  // :11-48
     else keys.insert(it.first);
   }
   if (!has_diagonal) return kFillMax;
+  const ShardSpec& sh = ShardSpec::Get();
+  const bool sharded_solve = sh.active();
   uint64_t fill = 0;
   for (const std::string& i : keys) {
     ImplType aik = ComputeType(A(i, k).impl().type(), A(k, k).impl().type());
     for (const std::string& j : keys) {
       ImplType type = ComputeType(aik, A(j, k).impl().type());
+      // Sharded solve: eliminating k must not create a non-elementwise block between two
+      // sharded keys - that block would couple the ranks' slices (and the local slice sizes
+      // would otherwise steer the ordering away from the single-GPU one).
+      if (sharded_solve && sh.IsSharded(i) && sh.IsSharded(j) && type != SCALAR_MATRIX &&
+          type != DIAGONAL_MATRIX)
+        return kFillForbidden;
       fill += Nonzeros(type, A(i, k).impl().m(), A(j, k).impl().m());
     }
   }
@@ -340,6 +391,9 @@ std::string NextKey(const BlockMatrix& A) {  // :51-64
   }
   EPS_CHECK_MSG(best_fill != kFillMax, "block LDL: no key with a diagonal block\n"
                                            << A.DebugString());
+  EPS_CHECK_MSG(best_fill != kFillForbidden,
+                "sharded solve: every elimination order couples the sharded keys (shard by the "
+                "other dimension)\n" << A.DebugString());
   return best_key;
 }
 
@@ -357,24 +411,44 @@ static BlockMatrix RemoveKey(BlockMatrix* A, const std::string& key) {  // :68-8
   return V;
 }
 
-BlockVector ForwardSub(const BlockMatrix& L, const std::vector<std::string>& keys, BlockVector b) {
-  for (auto j = keys.begin(); j != keys.end(); ++j) {  // :86-100
+namespace {
+
+// One triangular substitution over `order` (forward: elimination order, backward: reversed).
+// In a sharded solve a sharded source block contributes a partial sum to a replicated row;
+// those are kept apart and all-reduced once, right before the row is itself used as a source.
+template <class It>
+BlockVector Substitute(const BlockMatrix& L, It begin, It end, BlockVector b) {
+  const ShardSpec& sh = ShardSpec::Get();
+  const bool sharded_solve = sh.active();
+  BlockVector partial;
+  for (It j = begin; j != end; ++j) {
+    if (sharded_solve && partial.has_key(*j)) {
+      DVec p = partial.Mutable(*j);
+      Runtime::Get().comm()->AllReduceSum(p);
+      b.InsertOrAdd(*j, p);
+    }
     if (!b.has_key(*j)) continue;
     DVec bj = b(*j);
-    for (auto i = j + 1; i != keys.end(); ++i)
-      if (L.has_key(*i, *j)) b.InsertOrAddApply(*i, L(*i, *j).impl(), bj, -1.0);
+    const bool src_sharded = sharded_solve && sh.IsSharded(*j);
+    for (It i = j + 1; i != end; ++i) {
+      if (!L.has_key(*i, *j)) continue;
+      if (src_sharded && !sh.IsSharded(*i))
+        partial.InsertOrAddApply(*i, L(*i, *j).impl(), bj, -1.0);
+      else
+        b.InsertOrAddApply(*i, L(*i, *j).impl(), bj, -1.0);
+    }
   }
   return b;
 }
 
+}  // namespace
+
+BlockVector ForwardSub(const BlockMatrix& L, const std::vector<std::string>& keys, BlockVector b) {
+  return Substitute(L, keys.begin(), keys.end(), std::move(b));  // :86-100
+}
+
 BlockVector BackSub(const BlockMatrix& LT, const std::vector<std::string>& keys, BlockVector b) {
-  for (auto j = keys.rbegin(); j != keys.rend(); ++j) {  // :103-117
-    if (!b.has_key(*j)) continue;
-    DVec bj = b(*j);
-    for (auto i = j + 1; i != keys.rend(); ++i)
-      if (LT.has_key(*i, *j)) b.InsertOrAddApply(*i, LT(*i, *j).impl(), bj, -1.0);
-  }
-  return b;
+  return Substitute(LT, keys.rbegin(), keys.rend(), std::move(b));  // :103-117
 }
 
 void BlockCholesky::Compute(BlockMatrix A) {  // :119-133

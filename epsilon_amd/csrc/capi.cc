@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "admm.h"
+#include "comm.h"
 #include "kernels.h"
 #include "linear_map.h"
 #include "wire.h"
@@ -265,6 +266,50 @@ void eps_solver_destroy(eps_solver* s) {
     delete s;
   } catch (...) {
   }
+}
+
+int eps_comm_unique_id(void* out128) {
+  return Guard([&] {
+    EPS_CHECK(out128 != nullptr);
+    GetRcclUniqueId(out128);
+  });
+}
+
+int eps_comm_init_rccl(int rank, int world, const void* id128) {
+  return Guard([&] {
+    EPS_CHECK(id128 != nullptr && world >= 1 && rank >= 0 && rank < world);
+    Runtime& rt = Runtime::Get();
+    delete rt.comm();
+    rt.set_comm(nullptr);
+    rt.set_comm(NewRcclComm(rank, world, id128));
+  });
+}
+
+int eps_comm_init_callback(int rank, int world, eps_allreduce_fn fn, void* ctx) {
+  return Guard([&] {
+    EPS_CHECK(fn != nullptr && world >= 1 && rank >= 0 && rank < world);
+    Runtime& rt = Runtime::Get();
+    delete rt.comm();
+    rt.set_comm(nullptr);
+    rt.set_comm(NewHostCallbackComm(rank, world, fn, ctx));
+  });
+}
+
+int eps_comm_shutdown(void) {
+  return Guard([&] {
+    Runtime& rt = Runtime::Get();
+    rt.Sync();
+    delete rt.comm();
+    rt.set_comm(nullptr);
+    ShardSpec::Get().Clear();
+  });
+}
+
+int eps_shard_keys(const char* const* keys, size_t nkeys) {
+  return Guard([&] {
+    ShardSpec::Get().Clear();
+    for (size_t i = 0; i < nkeys; ++i) ShardSpec::Get().Add(keys[i]);
+  });
 }
 
 int eps_profile_enable(int on) {

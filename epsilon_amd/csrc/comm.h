@@ -1,0 +1,70 @@
+// Collective backend of the sharded solve (mode E1).
+//
+// The reference has no distributed mode at all.  Here one process drives one
+// GPU; a solve can be sharded over the ranks of a node: some block keys (variables, elementwise
+// constraint rows) are *sharded* - each rank holds a slice - the others are *replicated*.
+// Every map between two sharded keys must be elementwise (scalar / diagonal); a dense map from
+// a sharded key into a replicated key is a contraction over the sharded dimension and yields a
+// partial sum that is all-reduced.  For the headline lasso this is one all-reduce of m floats
+// per sweep (the forward substitution A u) plus one of a handful of doubles per residual check.
+//
+// Backends: RCCL over xGMI (dlopen'ed, so single-GPU runs never touch it) and a host callback
+// (staged through pinned memory) used by the multi-process tests that share one GPU or run
+// the collective through gloo.
+#pragma once
+
+#include <set>
+#include <string>
+
+#include "device.h"
+
+namespace eps {
+
+class Comm {
+ public:
+  virtual ~Comm() {}
+  virtual int rank() const = 0;
+  virtual int size() const = 0;
+  // In-place sum over ranks, ordered on the runtime stream.
+  virtual void AllReduceSum(void* dev_ptr, size_t count, DType dt) = 0;
+  void AllReduceSum(const DVec& v) { AllReduceSum(v.data(), static_cast<size_t>(v.n), v.dt); }
+};
+
+typedef void (*HostAllReduceFn)(void* host_buf, size_t count, int dtype, void* ctx);
+
+// RCCL: id = 128-byte ncclUniqueId from GetRcclUniqueId on rank 0.
+void GetRcclUniqueId(void* out128);
+Comm* NewRcclComm(int rank, int size, const void* id128);
+Comm* NewHostCallbackComm(int rank, int size, HostAllReduceFn fn, void* ctx);
+
+// Which block keys are sharded in the solve being set up / run on this process.
+class ShardSpec {
+ public:
+  static ShardSpec& Get();
+  void Clear() { keys_.clear(); }
+  void Add(const std::string& key) { keys_.insert(key); }
+  bool active() const;                       // a communicator with size > 1 is installed
+  bool IsSharded(const std::string& key) const {
+    return keys_.count(key) != 0 || local_.count(key) != 0;
+  }
+  const std::set<std::string>& keys() const { return keys_; }
+  // Keys whose meaning is local to one prox operator ("arg:<k>" rows of its H): set around that
+  // operator's Init / Apply by LocalShardScope.
+  void set_local(std::set<std::string> local) { local_ = std::move(local); }
+  const std::set<std::string>& local() const { return local_; }
+
+ private:
+  std::set<std::string> keys_;
+  std::set<std::string> local_;
+};
+
+struct LocalShardScope {
+  std::set<std::string> saved;
+  explicit LocalShardScope(const std::set<std::string>& local) {
+    saved = ShardSpec::Get().local();
+    ShardSpec::Get().set_local(local);
+  }
+  ~LocalShardScope() { ShardSpec::Get().set_local(saved); }
+};
+
+}  // namespace eps

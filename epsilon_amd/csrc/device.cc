@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "comm.h"
 #include "kernels.h"
 
 namespace eps {
@@ -28,10 +29,11 @@ Runtime::Runtime() {
   device_ = env ? std::atoi(env) % count : 0;
   EPS_HIP(hipSetDevice(device_));
   EPS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  EPS_HIP(hipMalloc(reinterpret_cast<void**>(&slots_dev_), kMaxSlots * sizeof(double)));
-  EPS_HIP(hipHostMalloc(reinterpret_cast<void**>(&slots_host_), kMaxSlots * sizeof(double),
+  EPS_HIP(hipMalloc(reinterpret_cast<void**>(&slots_dev_), 2 * kMaxSlots * sizeof(double)));
+  EPS_HIP(hipHostMalloc(reinterpret_cast<void**>(&slots_host_), 2 * kMaxSlots * sizeof(double),
                         hipHostMallocDefault));
-  EPS_HIP(hipMemsetAsync(slots_dev_, 0, kMaxSlots * sizeof(double), stream_));
+  EPS_HIP(hipMemsetAsync(slots_dev_, 0, 2 * kMaxSlots * sizeof(double), stream_));
+  std::memset(slots_host_, 0, 2 * kMaxSlots * sizeof(double));
 }
 
 Runtime::~Runtime() {}
@@ -95,10 +97,23 @@ int Runtime::NewSlot() {
   return slots_used_++;
 }
 
+void Runtime::ResetSlots() {
+  if (slots_used_ > 0) {
+    EPS_HIP(hipMemsetAsync(slots_dev_, 0, slots_used_ * sizeof(double), stream_));
+    EPS_HIP(hipMemsetAsync(slots_dev_ + kMaxSlots, 0, slots_used_ * sizeof(double), stream_));
+  }
+  slots_used_ = 0;
+}
+
 void Runtime::FetchSlots() {
   if (slots_used_ > 0) {
+    const bool sharded = ShardSpec::Get().active();
+    if (sharded) comm_->AllReduceSum(slots_dev_ + kMaxSlots, slots_used_, F64);
     EPS_HIP(hipMemcpyAsync(slots_host_, slots_dev_, slots_used_ * sizeof(double),
                            hipMemcpyDeviceToHost, stream_));
+    if (sharded)
+      EPS_HIP(hipMemcpyAsync(slots_host_ + kMaxSlots, slots_dev_ + kMaxSlots,
+                             slots_used_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
   EPS_HIP(hipStreamSynchronize(stream_));
 }

@@ -49,11 +49,14 @@ class Runtime {
 
   // Device scalar slots (doubles).  ResetSlots() rewinds the allocator; FetchSlots()
   // copies all used slots to the host with ONE async copy + stream sync.
+  // Each slot has a replicated part and a sharded part (partial sum over this rank's slice of
+  // sharded blocks); FetchSlots all-reduces the sharded parts in ONE collective.
   int NewSlot();
   double* SlotPtr(int i) { return slots_dev_ + i; }
-  void ResetSlots() { slots_used_ = 0; }
+  double* ShardSlotPtr(int i) { return slots_dev_ + kMaxSlots + i; }
+  void ResetSlots();  // rewinds and zeroes (on the stream)
   void FetchSlots();
-  double SlotValue(int i) const { return slots_host_[i]; }
+  double SlotValue(int i) const { return slots_host_[i] + slots_host_[kMaxSlots + i]; }
 
   void Sync();
 

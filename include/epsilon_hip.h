@@ -115,6 +115,27 @@ int eps_solver_result(eps_solver* s, eps_result** out);
 int eps_solver_timing(const eps_solver* s, double* init_seconds, double* loop_seconds);
 void eps_solver_destroy(eps_solver* s);
 
+/* ---- sharded solves over the GPUs of one node (one process per GPU) ------------------------- */
+/* No reference counterpart: the reference has no distributed mode.  Each rank
+ * passes its LOCAL problem: sharded variables / constraint rows hold this rank's slice, a data
+ * matrix feeding a replicated row from a sharded variable holds this rank's column slab.
+ * Sharded keys are declared once with eps_shard_keys; the solver then all-reduces exactly the
+ * contractions over sharded keys (lasso: m floats per sweep + a few doubles per residual
+ * check) and returns each rank's slice of the sharded variables. */
+#define EPS_UNIQUE_ID_BYTES 128
+/* rank 0: RCCL unique id to be distributed to the other ranks by the caller. */
+int eps_comm_unique_id(void* out128);
+/* all ranks: join the RCCL communicator (collective call). */
+int eps_comm_init_rccl(int rank, int world, const void* id128);
+/* all ranks: host-staged collective through a caller-provided function that sums `count`
+ * elements (dtype 0 = float, 1 = double) in place across ranks; used by tests that run the
+ * ranks on one GPU or over gloo. */
+typedef void (*eps_allreduce_fn)(void* host_buf, size_t count, int dtype, void* ctx);
+int eps_comm_init_callback(int rank, int world, eps_allreduce_fn fn, void* ctx);
+int eps_comm_shutdown(void);
+/* Replace the set of sharded block keys (variable ids and "constraint:<i>" rows). */
+int eps_shard_keys(const char* const* keys, size_t nkeys);
+
 /* ---- live kernel timing ---------------------------------------------------------------------- */
 /* When enabled, every hot kernel launch is bracketed by HIP events on the solver's stream.
  * eps_profile_dump writes one line per tag "tag count total_ms\n" (NUL-terminated, truncated

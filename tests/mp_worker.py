@@ -1,0 +1,96 @@
+"""Worker for the multi-process tests (launched once per rank with RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT in the environment).
+
+mode "oracle": numpy emulation of the column-sharded (E1) lasso sweep with gloo collectives -
+               checks the partitioning and where the collectives sit (runs on CPU).
+mode "hip"   : the real HIP solver, one rank per process, collectives through the host-callback
+               backend over gloo (ranks may share one GPU).
+Each rank writes its slice of the result to <out>/rank<r>.npz.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, out_dir, m, n, seed, max_iter = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+    import torch
+    import torch.distributed as dist
+    from epsilon_amd import dist as edist
+    from epsilon_amd import ir, problems, wire
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    A, b = problems.regression_data(m, n, seed=seed)
+    lam = 0.5 * np.abs(A.T.dot(b)).max()
+    lo, hi = edist.column_range(n, rank, world, align=1)
+    Ag = np.asfortranarray(A[:, lo:hi])
+    ng = hi - lo
+
+    def allreduce(x):
+        t = torch.from_numpy(np.ascontiguousarray(x))
+        dist.all_reduce(t)
+        return t.numpy()
+
+    if mode == "oracle":
+        # unrolled compiled-lasso sweep on this rank's column slab
+        G = allreduce(Ag.dot(Ag.T))                      # Gram: one all-reduce at Init
+        Minv = np.linalg.inv(np.eye(m) + 2 * G)
+        x0 = np.zeros(ng); x1 = np.zeros(ng); u = np.zeros(ng); y0 = np.zeros(ng); y1 = np.zeros(ng)
+        it = 0
+        status = None
+        while it < max_iter:
+            y1_prev = y1.copy()
+            u = u - y0 - y1
+            u = u + y0
+            t = allreduce(Ag.dot(u))                     # the one all-reduce per sweep
+            w = Minv.dot(b - t)
+            x0 = u + 2 * Ag.T.dot(w)
+            y0 = x0.copy()
+            u = u - y0
+            u = u + y1
+            v = -u
+            x1 = np.sign(v) * np.maximum(np.abs(v) - lam, 0)
+            y1 = -x1
+            u = u - y1
+            if it % 10 == 0:
+                s = allreduce(np.array([np.sum((x0 - x1) ** 2), np.sum((y1 - y1_prev) ** 2),
+                                        np.sum(x0 ** 2), np.sum(x1 ** 2), np.sum(u ** 2)]))
+                r, sn = np.sqrt(s[0]), np.sqrt(s[1])
+                ep = 1e-4 * np.sqrt(n) + 1e-2 * max(np.sqrt(s[2]), np.sqrt(s[3]))
+                ed = 1e-4 * np.sqrt(2 * n) + 1e-2 * np.sqrt(2 * s[4])
+                status = (it, r, sn, ep, ed)
+                if r <= ep and sn <= ed:
+                    break
+            it += 1
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x0=x0, x1=x1, lo=lo, hi=hi,
+                 status=np.array(status))
+    else:
+        from epsilon_amd import _solve
+        dtype = os.environ.get("EPS_TEST_DTYPE", "f64")
+        _solve.set_option("dtype", dtype)
+        edist.init_comm(rank, world, backend="host")
+        prob = problems.lasso_ir(ir.dense_matrix(Ag), ir.constant(b), lam, ng)
+        edist.mark_sharded(None, prob)
+        params = wire.SolverParams(max_iterations=max_iter)
+        st, x = _solve.solve(prob.SerializeToString(), [], params.SerializeToString(),
+                             prob.expression_data())
+        S = wire.SolverStatus.FromString(st)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+                 x0=np.frombuffer(x["var:x"]), x1=np.frombuffer(x["separate:var:x:norm_1"]),
+                 lo=lo, hi=hi,
+                 status=np.array([S.num_iterations, S.residuals.r_norm, S.residuals.s_norm,
+                                  S.residuals.epsilon_primal, S.residuals.epsilon_dual]),
+                 state=S.state)
+        _solve.comm_shutdown()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,34 @@
+"""Single-rank RCCL smoke: the sharded code path with a real RCCL communicator of size 1
+(EPSILON_HIP_FORCE_SHARDED=1).  Prints 'RCCL_OK <max abs diff vs oracle>'."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["EPSILON_HIP_FORCE_SHARDED"] = "1"
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29631")
+
+import torch.distributed as dist  # noqa: E402
+
+from epsilon_amd import _solve, problems, wire  # noqa: E402
+from epsilon_amd import dist as edist  # noqa: E402
+from oracle import epsilon_oracle as orc  # noqa: E402
+
+dist.init_process_group("gloo", rank=0, world_size=1)
+_solve.set_option("dtype", "f64")
+edist.init_comm(0, 1, backend="rccl")
+prob, info = problems.lasso(40, 101, seed=3)
+edist.mark_sharded(None, prob)
+pb, sb = prob.SerializeToString(), wire.SolverParams().SerializeToString()
+st, x = _solve.solve(pb, [], sb, prob.expression_data())
+st_o, x_o = orc.solve(pb, [], sb, prob.expression_data())
+a, b = wire.SolverStatus.FromString(st), wire.SolverStatus.FromString(st_o)
+assert a.state == b.state and a.num_iterations == b.num_iterations, (a, b)
+d = max(np.abs(np.frombuffer(x[k]) - np.frombuffer(x_o[k])).max() for k in x_o)
+assert d < 1e-9, d
+_solve.comm_shutdown()
+dist.destroy_process_group()
+print("RCCL_OK %.3e" % d)
