@@ -38,13 +38,17 @@ def regression_data(m, n, rho=1.0, sigma=0.05, seed=0):
     return A, b
 
 
-def lasso_ir(A_map, b_expr, lam, n):
-    """sum_square(A x - b) + lam*norm_1(y)  s.t.  x - y = 0   (docs/solver.rst:33-39).
+# The separate pass gives the FIRST function sharing a variable (sum_square) a copy named
+# "separate:<old id>:<function node>", tied to the original by zero(copy - original); the user's
+# variable stays with norm_1 (reference compiler/transforms/separate.py:64-85).
+LASSO_COPY = "separate:var:x:sum_square"
+LASSO_VAR = "var:x"
 
-    `x` is the copy the separate pass makes for the first function sharing the variable
-    (compiler/transforms/separate.py:64-85)."""
-    x = ir.variable(n, 1, "var:x")
-    y = ir.variable(n, 1, "separate:var:x:norm_1")
+
+def lasso_ir(A_map, b_expr, lam, n):
+    """sum_square(A x' - b) + lam*norm_1(x)  s.t.  x' - x = 0   (docs/solver.rst:33-39)."""
+    x = ir.variable(n, 1, LASSO_COPY)
+    y = ir.variable(n, 1, LASSO_VAR)
     m = A_map.m
     f0 = ir.prox(ProxFunction.SUM_SQUARE,
                  ir.add(ir.linear_map(A_map, x),

@@ -82,7 +82,7 @@ def main():
                              prob.expression_data())
         S = wire.SolverStatus.FromString(st)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
-                 x0=np.frombuffer(x["var:x"]), x1=np.frombuffer(x["separate:var:x:norm_1"]),
+                 x0=np.frombuffer(x["separate:var:x:sum_square"]), x1=np.frombuffer(x["var:x"]),
                  lo=lo, hi=hi,
                  status=np.array([S.num_iterations, S.residuals.r_norm, S.residuals.s_norm,
                                   S.residuals.epsilon_primal, S.residuals.epsilon_dual]),

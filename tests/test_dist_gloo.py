@@ -24,7 +24,7 @@ def test_column_range_covers_everything():
 
 def test_lasso_sharded_keys():
     prob, _ = problems.lasso(8, 20, seed=0)
-    assert edist.lasso_sharded_keys(prob) == ["separate:var:x:norm_1", "var:x", "constraint:0"]
+    assert edist.lasso_sharded_keys(prob) == ["separate:var:x:sum_square", "var:x", "constraint:0"]
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -40,5 +40,5 @@ def test_sharded_sweep_equals_single_process(tmp_path, world):
         np.testing.assert_allclose(s[1:], [S.residuals.r_norm, S.residuals.s_norm,
                                            S.residuals.epsilon_primal, S.residuals.epsilon_dual],
                                    rtol=1e-9)
-    np.testing.assert_allclose(x0, np.frombuffer(x["var:x"]), rtol=1e-9, atol=1e-11)
-    np.testing.assert_allclose(x1, np.frombuffer(x["separate:var:x:norm_1"]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(x0, np.frombuffer(x["separate:var:x:sum_square"]), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(x1, np.frombuffer(x["var:x"]), rtol=1e-9, atol=1e-11)

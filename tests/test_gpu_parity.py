@@ -337,8 +337,8 @@ def test_sharded_hip_solve_matches_single_gpu(solve_mod, tmp_path, world):
         np.testing.assert_allclose(s[1:], [S.residuals.r_norm, S.residuals.s_norm,
                                            S.residuals.epsilon_primal, S.residuals.epsilon_dual],
                                    rtol=1e-8)
-    np.testing.assert_allclose(x0, np.frombuffer(x["var:x"]), rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(x1, np.frombuffer(x["separate:var:x:norm_1"]), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(x0, np.frombuffer(x["separate:var:x:sum_square"]), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(x1, np.frombuffer(x["var:x"]), rtol=1e-8, atol=1e-10)
 
 
 def test_rccl_backend_single_rank(solve_mod):

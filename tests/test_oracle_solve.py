@@ -1,0 +1,106 @@
+"""End-to-end pins of the oracle's ADMM drivers, after the reference's
+python/epopt/solve_test.py:26-83: at termination the objective must be within
+(1 + 1e-2)*opt + 1e-4 of an independent solve, for all three parameter sets the reference
+uses that this build covers (PROX_ADMM, PROX_ADMM_TWO_BLOCK)."""
+
+import numpy as np
+import pytest
+from scipy import optimize
+
+from epsilon_amd import problems, wire
+from oracle import c_oracle
+from oracle import epsilon_oracle as orc
+
+
+def solve(prob, **kw):
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams(**kw).SerializeToString(),
+                      prob.expression_data())
+    return wire.SolverStatus.FromString(st), {k: np.frombuffer(v) for k, v in x.items()}
+
+
+def lasso_reference_optimum(A, b, lam, iters=20000):
+    """Independent high-accuracy lasso solve (FISTA)."""
+    L = 2 * np.linalg.norm(A, 2) ** 2
+    x = np.zeros(A.shape[1])
+    z, t = x.copy(), 1.0
+    for _ in range(iters):
+        g = 2 * A.T @ (A @ z - b)
+        xn = z - g / L
+        xn = np.sign(xn) * np.maximum(np.abs(xn) - lam / L, 0)
+        tn = (1 + np.sqrt(1 + 4 * t * t)) / 2
+        z = xn + (t - 1) / tn * (xn - x)
+        x, t = xn, tn
+    return problems.lasso_objective(A, b, lam, x)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("shape", [(5, 20), (200, 500), (40, 15)])
+def test_lasso_objective(solver, shape):  # solve_test.py: lasso m=5, n=20 (+ the config-1 size)
+    prob, info = problems.lasso(*shape, seed=0)
+    S, x = solve(prob, solver=solver)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    obj = problems.lasso_objective(info["A"], info["b"], info["lam"], x["var:x"])
+    opt = lasso_reference_optimum(info["A"], info["b"], info["lam"])
+    assert obj <= opt * (1 + 1e-2) + 1e-4
+
+
+def test_stopping_iterations_match_survey_probe():
+    """SURVEY.md 3.3 / BASELINE.md section 2: the compiled reference stops lasso 200x500 at
+    iteration 30 (PROX_ADMM) and 40 (TWO_BLOCK); the restatement does the same on an
+    instance of the same distribution."""
+    prob, _ = problems.lasso(200, 500, seed=0)
+    assert solve(prob, solver=0)[0].num_iterations == 30
+    assert solve(prob, solver=1)[0].num_iterations == 40
+
+
+def test_c_oracle_equals_generic_oracle():
+    """oracle/lasso_sweep.c (the cpu_baseline leg) == the generic restatement, sweep for sweep."""
+    prob, info = problems.lasso(60, 150, seed=1)
+    A = np.asfortranarray(info["A"])
+    Minv = np.asfortranarray(np.linalg.inv(np.eye(60) + 2 * A @ A.T))
+    for k in (1, 2, 3, 10):
+        st = c_oracle.LassoState(150)
+        c_oracle.lasso_run(A, Minv, info["b"], info["lam"], st, k, abs_tol=0, rel_tol=0)
+        S, x = solve(prob, max_iterations=k)
+        np.testing.assert_allclose(st.x0, x["separate:var:x:sum_square"], atol=1e-12)
+        np.testing.assert_allclose(st.x1, x["var:x"], atol=1e-12)
+    st = c_oracle.LassoState(150)
+    c_oracle.lasso_run(A, Minv, info["b"], info["lam"], st, 10000)
+    S, x = solve(prob)
+    assert st.optimal and st.iter == S.num_iterations
+    np.testing.assert_allclose(st.resid, [S.residuals.r_norm, S.residuals.s_norm,
+                                          S.residuals.epsilon_primal, S.residuals.epsilon_dual], rtol=1e-10)
+
+
+def test_tv_1d_problem():  # solve_test.py:52 tv_1d n=10 (+ a larger one)
+    for n in (10, 200):
+        prob, info = problems.tv_1d(n, seed=0)
+        S, x = solve(prob)
+        obj = problems.tv_1d_objective(info["b"], info["lam"], x["var:x"])
+        opt = problems.tv_1d_objective(info["b"], info["lam"], orc.tv1d_prox(info["b"], info["lam"]))
+        assert obj <= opt * (1 + 1e-2) + 1e-4
+
+
+def test_robust_pca_problem():  # solve_test.py: robust_pca n=10
+    prob, info = problems.robust_pca(10, r=2, seed=0)
+    S, x = solve(prob)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    L = x["var:L"].reshape((10, 10), order="F")
+    Sm = x["var:S"].reshape((10, 10), order="F")
+    assert np.abs(L + Sm - info["M"]).max() < 0.2
+    # objective no worse than the trivial feasible points L = M or S = M
+    obj = problems.robust_pca_objective(info["lam"], L, info["M"] - L)
+    assert obj <= min(problems.robust_pca_objective(info["lam"], info["M"], 0 * info["M"]),
+                      problems.robust_pca_objective(info["lam"], 0 * info["M"], info["M"])) * 1.01
+
+
+def test_multiclass_hinge_problem():
+    X, Y = problems.multiclass_hinge_data(30, 8, 3, seed=0)
+    prob, info = problems.multiclass_hinge(X, Y, lam=0.1)
+    S, x = solve(prob)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    Th = x["var:Theta"].reshape((8, 3), order="F")
+    obj = problems.multiclass_hinge_objective(X, Y, 0.1, Th)
+    f = lambda t: problems.multiclass_hinge_objective(X, Y, 0.1, t.reshape(8, 3))
+    best = min(optimize.minimize(f, Th.ravel(), method="Powell", options=dict(maxiter=20000)).fun, obj)
+    assert obj <= best * (1 + 2e-2) + 1e-3
