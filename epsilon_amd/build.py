@@ -21,6 +21,7 @@ HOST_SOURCES = ["wire.cc", "device.cc", "comm.cc", "linear_map.cc", "block.cc", 
 # the same branch and produce the same bits as a plain IEEE evaluation.
 DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_prox.hip", ["-ffp-contract=off"]),
+                  ("kernels_fused.hip", ["-ffp-contract=off"]),
                   ("kernels_gemv.hip", []),
                   ("kernels_gemm.hip", []),
                   ("kernels_factor.hip", [])]

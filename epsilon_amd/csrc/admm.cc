@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "comm.h"
 #include "kernels.h"
@@ -150,6 +151,7 @@ class ProxADMMSolver final : public Solver {
     finished_ = false;
     status_ = pb::SolverStatus();
     initialized_ = true;
+    TryEnableFused();
     if (params_.verbose && log_) {
       char buf[128];
       std::snprintf(buf, sizeof(buf), "constraints, m = %lld, variables, n = %lld",
@@ -225,7 +227,123 @@ class ProxADMMSolver final : public Solver {
     }
   }
 
+  // ---- fused sweep: "least squares + separable threshold" (kernels_fused.hip) ------------------
+  // Recognised structure (the compiled lasso): two terms [SUM_SQUARE with a dense
+  // argument map, scaled-zone prox with scalar maps], one consensus constraint a0 x' + a1 x = 0
+  // with a0 = 1 and no constant.  The sweep is then: one fused pass over A (back substitution of
+  // this sweep, elementwise chain, forward substitution of the next sweep), a partial-sum
+  // reduction (+ the all-reduce when sharded) and the apply of the cached inverse.
+  void TryEnableFused() {
+    fused_ = false;
+    const char* env = std::getenv("EPSILON_HIP_FUSED");
+    if (env && env[0] == '0') return;
+    if (data_->dtype() != F32 || N_ != 2 || problem_.constraint.size() != 1) return;
+    if (!b_.data().empty()) return;
+    FusedState f;
+    if (!prox_[0]->DescribeLeastSquares(&f.ls) || !prox_[1]->DescribeScaledZone(&f.sz)) return;
+    const std::string ck = affine::constraint_key(0);
+    if (f.ls.constraint_key != ck || f.sz.constraint_key != ck) return;
+    if (A_.data().size() != 2 || !A_.has_key(ck, f.ls.var_key) || !A_.has_key(ck, f.sz.var_key))
+      return;
+    const LinearMap& A0 = A_(ck, f.ls.var_key);
+    const LinearMap& A1 = A_(ck, f.sz.var_key);
+    if (A0.impl().type() != SCALAR_MATRIX || A1.impl().type() != SCALAR_MATRIX) return;
+    if (GetScalar(A0) != 1.0) return;
+    f.a1 = GetScalar(A1);
+    const DenseMatrixImpl& L = *f.ls.L_arg_var;
+    if (L.trans()) return;
+    f.m = L.rows();
+    f.n = L.cols();
+    if (A0.impl().n() != f.n || A1.impl().n() != f.n) return;
+    if (!k::LassoFusedSupported(f.m, f.n, L.data(), L.rows())) return;
+    if (f.ls.rhs_arg.n != 0 && f.ls.rhs_arg.n != f.m) return;
+    const DType dt = F32;
+    auto state = [&](const BlockVector& src, const std::string& key) {
+      DVec v = DVec::Zeros(f.n, dt);
+      if (src.has_key(key)) k::Copy(v, src(key));
+      return v;
+    };
+    f.x0 = state(x_[0], f.ls.var_key);
+    f.x1 = state(x_[1], f.sz.var_key);
+    f.y0 = state(y_[0], ck);
+    f.y1 = state(y_[1], ck);
+    f.u = state(u_, ck);
+    f.y1prev = DVec::Zeros(f.n, dt);
+    f.w = DVec::Zeros(f.m, dt);
+    f.p = DVec::Zeros(f.m, dt);
+    f.grid = k::LassoFusedGrid(f.n);
+    f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
+    fs_ = f;
+    // the generic containers become views of the fused state
+    x_[0] = BlockVector();
+    x_[0].Set(fs_.ls.var_key, fs_.x0);
+    x_[1] = BlockVector();
+    x_[1].Set(fs_.sz.var_key, fs_.x1);
+    y_[0] = BlockVector();
+    y_[0].Set(ck, fs_.y0);
+    y_[1] = BlockVector();
+    y_[1].Set(ck, fs_.y1);
+    u_ = BlockVector();
+    u_.Set(ck, fs_.u);
+    y_prev_.assign(2, BlockVector());
+    y_prev_[1].Set(ck, fs_.y1prev);
+    fused_ = true;
+    FusedForward(/*from_state=*/true);
+  }
+
+  // p = rhs_arg - L(arg,var) v0 (all-reduced when sharded), w = Dinv_arg p.
+  void FusedForward(bool from_state) {
+    FusedState& f = fs_;
+    const DenseMatrixImpl& L = *f.ls.L_arg_var;
+    if (from_state) {
+      // v0 = ((u - y0) - y1) + y0 of the current state, then the generic forward product
+      DVec v0 = f.u.Clone();
+      k::Axpby(v0, -1.0, f.y0, 1.0);
+      k::Axpby(v0, -1.0, f.y1, 1.0);
+      k::Axpby(v0, 1.0, f.y0, 1.0);
+      L.Apply(-1.0, v0, 0.0, f.p);
+    } else {
+      k::ReducePartials(f.m, f.grid, f.tpart, -L.scale(), 0.0, f.p);
+    }
+    const ShardSpec& sh = ShardSpec::Get();
+    if (sh.active() && sh.IsSharded(f.ls.var_key)) Runtime::Get().comm()->AllReduceSum(f.p);
+    if (f.ls.rhs_arg.n != 0) k::Axpby(f.p, 1.0, f.ls.rhs_arg, 1.0);
+    f.ls.Dinv_arg->Apply(1.0, f.p, 0.0, f.w);
+  }
+
+  void FusedSweep() {
+    FusedState& f = fs_;
+    const DenseMatrixImpl& L = *f.ls.L_arg_var;
+    k::LassoFusedArgs a;
+    a.m = f.m;
+    a.n = f.n;
+    a.lda = L.rows();
+    a.A = L.data();
+    a.w = f.w;
+    a.kappa = -L.scale();
+    a.Bs = f.sz.Bs;
+    a.Cs = f.sz.Cs;
+    a.a1 = f.a1;
+    a.lam = f.sz.lam;
+    a.sz_alpha = f.sz.alpha;
+    a.sz_beta = f.sz.beta;
+    a.sz_M = f.sz.M;
+    a.u = f.u;
+    a.x0 = f.x0;
+    a.x1 = f.x1;
+    a.y0 = f.y0;
+    a.y1 = f.y1;
+    a.y1prev = f.y1prev;
+    a.tpart = f.tpart;
+    k::LassoFusedPass(a);
+    FusedForward(/*from_state=*/false);
+  }
+
   void Sweep() override {  // :135-147
+    if (fused_) {
+      FusedSweep();
+      return;
+    }
     y_prev_ = y_;  // shallow: blocks are replaced, never mutated, below
     u_ -= b_;
     for (int i = 0; i < N_; ++i) u_ -= y_[i];
@@ -284,6 +402,16 @@ class ProxADMMSolver final : public Solver {
   std::vector<BlockMatrix> AiT_;
   std::vector<std::unique_ptr<ProxOperator>> prox_;
   std::vector<std::set<std::string>> arg_shards_;
+  struct FusedState {
+    LeastSquaresDesc ls;
+    ScaledZoneDesc sz;
+    double a1 = 0;
+    int64_t m = 0, n = 0;
+    int grid = 0;
+    DVec u, x0, x1, y0, y1, y1prev, w, p, tpart;
+  };
+  bool fused_ = false;
+  FusedState fs_;
   BlockVector u_;
   std::vector<BlockVector> x_, y_, y_prev_;
 };

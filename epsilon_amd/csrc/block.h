@@ -111,6 +111,8 @@ class BlockCholesky {
   void Compute(BlockMatrix A);
   BlockVector Solve(const BlockVector& b) const;
   const std::vector<std::string>& order() const { return p_; }
+  const BlockMatrix& L() const { return L_; }
+  const BlockMatrix& D_inv() const { return D_inv_; }
 
  private:
   std::vector<std::string> p_;

@@ -110,6 +110,8 @@ int eps_set_option(const char* key, const char* value) {
       setenv("EPSILON_HIP_DEVICE", value, 1);
     } else if (std::strcmp(key, "gemm") == 0) {
       setenv("EPSILON_HIP_GEMM", value, 1);
+    } else if (std::strcmp(key, "fused") == 0) {
+      setenv("EPSILON_HIP_FUSED", value, 1);
     } else {
       EPS_FATAL("unknown option " << key);
     }
@@ -392,6 +394,97 @@ int eps_linear_map_inverse(const void* linear_map, size_t len, const eps_blob* d
     std::vector<double> D = A.impl().AsDenseHost();
     EPS_CHECK_MSG(D.size() <= dense_capacity, "dense output buffer too small");
     std::memcpy(dense, D.data(), D.size() * sizeof(double));
+  });
+}
+
+}  // extern "C"
+
+namespace {
+template <class F> double TimeLaunches(int iters, F f) {
+  Runtime& rt = Runtime::Get();
+  for (int i = 0; i < 2; ++i) f();
+  hipEvent_t a, b;
+  EPS_HIP(hipEventCreate(&a));
+  EPS_HIP(hipEventCreate(&b));
+  EPS_HIP(hipEventRecord(a, rt.stream()));
+  for (int i = 0; i < iters; ++i) f();
+  EPS_HIP(hipEventRecord(b, rt.stream()));
+  EPS_HIP(hipEventSynchronize(b));
+  float ms = 0;
+  EPS_HIP(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return ms / iters;
+}
+// deterministic non-trivial fill: v[i] = ((i * 2654435761) mod 1024) / 1024 - 0.5
+DVec Synthetic(int64_t n, DType dt, double scale) {
+  std::vector<double> h(std::min<int64_t>(n, 1 << 20));
+  for (size_t i = 0; i < h.size(); ++i)
+    h[i] = scale * (static_cast<double>((i * 2654435761ull) & 1023) / 1024.0 - 0.5);
+  DVec chunk = DVec::FromHost(h.data(), static_cast<int64_t>(h.size()), dt);
+  if (n <= static_cast<int64_t>(h.size())) return chunk;
+  DVec v = DVec::Empty(n, dt);
+  for (int64_t off = 0; off < n; off += chunk.n) {
+    int64_t len = std::min<int64_t>(chunk.n, n - off);
+    k::Copy(v.Slice(off, len), chunk.Slice(0, len));
+  }
+  return v;
+}
+}  // namespace
+
+extern "C" {
+
+int eps_bench_gemv(int trans, int64_t rows, int64_t cols, int iters, double* ms_avg) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    DVec A = Synthetic(rows * cols, dt, 1.0);
+    DVec x = Synthetic(trans ? rows : cols, dt, 1.0);
+    DVec y = DVec::Zeros(trans ? cols : rows, dt);
+    *ms_avg = TimeLaunches(iters, [&] { k::Gemv(trans != 0, rows, cols, 1.0, A, rows, x, 0.0, y); });
+  });
+}
+
+int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int lower_only,
+                   int iters, double* ms_avg) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    DVec A = Synthetic(M * K, dt, 1.0);
+    DVec B = Synthetic(K * N, dt, 1.0);
+    DVec C = DVec::Zeros(M * N, dt);
+    const int64_t lda = trans_a ? K : M, ldb = trans_b ? N : K;
+    *ms_avg = TimeLaunches(iters, [&] {
+      k::Gemm(trans_a != 0, trans_b != 0, M, N, K, 1.0, A, lda, B, ldb, 0.0, C, M, lower_only != 0);
+    });
+  });
+}
+
+int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    DVec G = Synthetic(n * n, dt, 1.0);
+    DVec W0 = DVec::Zeros(n * n, dt);
+    k::Gemm(false, true, n, n, n, 1.0 / n, G, n, G, n, 0.0, W0, n, false);
+    k::AddDiag(W0, n, n, 1.0, nullptr);
+    DVec W = DVec::Empty(n * n, dt);
+    Runtime& rt = Runtime::Get();
+    double total = 0;
+    for (int i = 0; i < iters + 1; ++i) {
+      k::Copy(W, W0);
+      rt.Sync();
+      hipEvent_t a, b;
+      EPS_HIP(hipEventCreate(&a));
+      EPS_HIP(hipEventCreate(&b));
+      EPS_HIP(hipEventRecord(a, rt.stream()));
+      k::SpdInverseInPlace(W, n);
+      EPS_HIP(hipEventRecord(b, rt.stream()));
+      EPS_HIP(hipEventSynchronize(b));
+      float e = 0;
+      EPS_HIP(hipEventElapsedTime(&e, a, b));
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+      if (i > 0) total += e;
+    }
+    *ms_avg = total / iters;
   });
 }
 

@@ -120,7 +120,7 @@ void Runtime::FetchSlots() {
 
 void Runtime::Sync() { EPS_HIP(hipStreamSynchronize(stream_)); }
 
-void Runtime::ProfBegin(const std::string& tag) {
+size_t Runtime::ProfBegin(const std::string& tag) {
   ProfPending e;
   e.tag = tag;
   for (hipEvent_t* ev : {&e.a, &e.b}) {
@@ -133,11 +133,14 @@ void Runtime::ProfBegin(const std::string& tag) {
   }
   EPS_HIP(hipEventRecord(e.a, stream_));
   prof_pending_.push_back(e);
+  ++prof_open_;
+  return prof_pending_.size() - 1;
 }
 
-void Runtime::ProfEnd() {
-  EPS_HIP(hipEventRecord(prof_pending_.back().b, stream_));
-  if (prof_pending_.size() >= 8192) ProfCollect();
+void Runtime::ProfEnd(size_t index) {
+  EPS_HIP(hipEventRecord(prof_pending_[index].b, stream_));
+  --prof_open_;
+  if (prof_open_ == 0 && prof_pending_.size() >= 8192) ProfCollect();
 }
 
 void Runtime::ProfCollect() {
@@ -167,11 +170,15 @@ ProfScope::ProfScope(const char* name, int64_t a, int64_t b) {
   std::string tag = name;
   if (a >= 0) tag += ":" + std::to_string(a);
   if (b >= 0) tag += "x" + std::to_string(b);
-  rt.ProfBegin(tag);
+  index = rt.ProfBegin(tag);
 }
 
 ProfScope::~ProfScope() {
-  if (on) Runtime::Get().ProfEnd();
+  if (!on) return;
+  try {
+    Runtime::Get().ProfEnd(index);
+  } catch (...) {  // never throw out of a destructor (may run during unwinding)
+  }
 }
 
 static thread_local DType g_current_dtype = F32;

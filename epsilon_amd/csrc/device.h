@@ -63,8 +63,8 @@ class Runtime {
   // ---- live kernel timing (HIP events on this stream; off unless eps_profile_enable) -------
   bool profiling() const { return profiling_; }
   void set_profiling(bool on) { profiling_ = on; }
-  void ProfBegin(const std::string& tag);
-  void ProfEnd();
+  size_t ProfBegin(const std::string& tag);  // returns the entry index for ProfEnd
+  void ProfEnd(size_t index);
   void ProfCollect();  // synchronises, folds finished event pairs into the totals
   void ProfReset();
   struct ProfTotal { int64_t count = 0; double ms = 0; };
@@ -91,6 +91,7 @@ class Runtime {
   bool profiling_ = false;
   struct ProfPending { std::string tag; hipEvent_t a, b; };
   std::vector<ProfPending> prof_pending_;
+  int prof_open_ = 0;
   std::vector<hipEvent_t> prof_free_;
   std::map<std::string, ProfTotal> prof_totals_;
 };
@@ -98,6 +99,7 @@ class Runtime {
 // RAII scope around one kernel launch (or a short launch sequence) for live timing.
 struct ProfScope {
   bool on;
+  size_t index = 0;
   explicit ProfScope(const char* name, int64_t a = -1, int64_t b = -1);
   ~ProfScope();
 };

@@ -35,6 +35,25 @@ void Dot(const DVec& x, const DVec& y, double* slot, bool accumulate);
 void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, int64_t lda,
           const DVec& x, double beta, const DVec& y);
 
+// y[r] = alpha * sum_{k < nparts} partial[k*rows + r] + beta*y[r], fixed summation order.
+void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
+                    const DVec& y);
+
+// ---- fused lasso sweep: one pass over A per ADMM sweep (kernels_fused.hip) ------------------
+struct LassoFusedArgs {
+  int64_t m = 0, n = 0, lda = 0;
+  DVec A;        // m x n column-major
+  DVec w;        // m: the block-diagonal-scaled forward-substitution result of this sweep
+  double kappa = 0;                 // x0 = v0 + kappa * (A^T w)
+  double Bs = 0, Cs = 0, a1 = 0;    // prox-1 pre / post scaling, y1 = a1 * x1
+  double lam = 0, sz_alpha = 1, sz_beta = 1, sz_M = 0;
+  DVec u, x0, x1, y0, y1, y1prev;   // n each, updated in place
+  DVec tpart;                       // LassoFusedGrid(n) * m: per-workgroup partials of A v0'
+};
+bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda);
+int LassoFusedGrid(int64_t n);
+void LassoFusedPass(const LassoFusedArgs& args);
+
 // ---- K4: dense mat-mat (reference linear/linear_map_multiply.cc:14-37 dgemm_) -------------
 // C (M x N, ldc) = alpha * op(A) (M x K) * op(B) (K x N) + beta * C ; column-major.
 // lower_only: compute only tiles touching the lower triangle (SYRK-style); the caller

@@ -1,0 +1,231 @@
+// Fused sweep kernel for "least squares + separable threshold" problems (the compiled lasso,
+// SURVEY.md 3.3): ONE pass over the data matrix per ADMM sweep instead of two.
+//
+// In the reference a sweep touches A twice - `A v` in the forward substitution and `A^T w` in
+// the back substitution of the least-squares prox (reference vector/block_cholesky.cc:86-117 via
+// linear/dense_matrix_impl.cc:63) - with the elementwise NORM_1 prox and the u/y bookkeeping of
+// prox_admm.cc:135-147 in between.  Everything between `A^T w` of sweep k and `A v` of sweep k+1
+// is elementwise in the column index j.  So for each column j, while it sits in registers:
+//
+//     d_j   = A[:,j] . w                         (back substitution of sweep k)
+//     x0_j  = v0_j + kappa d_j ;  y0, u, prox-1 (two-sided threshold), y1, u  ... -> v0'_j
+//     t'   += A[:,j] * v0'_j                     (forward substitution of sweep k+1)
+//
+// The elementwise chain repeats the reference's operations one by one, in order, one rounding
+// each (this file is compiled with -ffp-contract=off), so given d_j the state is bit-identical
+// to the unfused path.  HBM traffic per sweep drops from (2mn + m^2)s to (mn + m^2)s.
+//
+// Geometry: 256 threads own all m rows (thread t: rows 4(t + 256q), q < NR - 16 B loads,
+// coalesced 4 KiB per q); w and the partial t' stay in registers for the whole launch; columns
+// are processed in pairs so 2*NR loads per thread are in flight; the two dot products are
+// reduced with wave shuffles + LDS in a fixed order (deterministic); per-workgroup partial t'
+// vectors are summed by ReducePartials.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ inline float WaveSumF(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ inline float ScaledZoneOne(float v, float lam, float alpha, float beta, float M) {
+  // reference prox/scaled_zone.cc:90-101 with C = 0
+  float xi = v;
+  if (fabsf(xi) <= M) return xi;
+  if (xi > M + lam * alpha) return xi - lam * alpha;
+  if (xi < -M - lam * beta) return xi + lam * beta;
+  if (xi > 0.0f) return M;
+  return -M;
+}
+
+struct FusedScalars {
+  float kappa;  // x0 = v0 + kappa * d
+  float Bs, Cs, a1;
+  float lam, alpha, beta, M;
+};
+
+// One column's elementwise chain.  Returns v0' (input of the next sweep's forward pass).
+__device__ inline float ChainOne(float d, const FusedScalars& c, float u, float y0p, float y1p,
+                                 float* x0o, float* x1o, float* y0o, float* y1o, float* uo) {
+  // sweep start: u -= y0; u -= y1; then term 0: u += y0       (prox_admm.cc:137-142)
+  float v0 = ((u - y0p) - y1p) + y0p;
+  float x0 = c.kappa * d + v0;        // back substitution epilogue: alpha*acc + 1*y
+  float y0 = x0;                       // y_0 = A_ x_0 with A_(c0,x) = I
+  float u1 = v0 - y0;                  // u -= y_0
+  float u2 = u1 + y1p;                 // term 1: u += y_1
+  float vin = c.Bs * u2;               // VectorProx: B v (+ g = 0)      (vector_prox.cc:141)
+  float xz = ScaledZoneOne(vin, c.lam, c.alpha, c.beta, c.M);
+  float x1 = c.Cs * xz;                // C (x - g)                       (vector_prox.cc:145)
+  float y1 = c.a1 * x1;                // y_1 = A_ x_1
+  float u3 = u2 - y1;                  // u -= y_1
+  *x0o = x0;
+  *x1o = x1;
+  *y0o = y0;
+  *y1o = y1;
+  *uo = u3;
+  // next sweep's prox-0 input
+  return ((u3 - y0) - y1) + y0;
+}
+
+template <int NR>
+__global__ __launch_bounds__(kBlock, 2) void LassoFusedKernel(
+    int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
+    FusedScalars c, float* u, float* x0, float* x1, float* y0, float* y1, float* y1prev,
+    float* __restrict__ tpart) {
+  __shared__ float red[2][kBlock / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 wv[NR], tp[NR];
+  int64_t row[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    row[q] = (static_cast<int64_t>(q) * kBlock + tid) * 4;
+    wv[q] = row[q] < m ? *reinterpret_cast<const float4*>(w + row[q]) : make_float4(0, 0, 0, 0);
+    tp[q] = make_float4(0, 0, 0, 0);
+  }
+  const int64_t npairs = (n + 1) / 2;
+  int par = 0;
+  for (int64_t jp = blockIdx.x; jp < npairs; jp += gridDim.x, par ^= 1) {
+    const int64_t j = 2 * jp;
+    const bool has2 = j + 1 < n;
+    const float* c0p = A + j * lda;
+    const float* c1p = c0p + lda;
+    float4 a0[NR], a1[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      a0[q] = row[q] < m ? *reinterpret_cast<const float4*>(c0p + row[q]) : make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      a1[q] = (has2 && row[q] < m) ? *reinterpret_cast<const float4*>(c1p + row[q])
+                                   : make_float4(0, 0, 0, 0);
+    // per-column state (same address in every lane: broadcast loads)
+    const float uj0 = u[j], y0j0 = y0[j], y1j0 = y1[j];
+    const int64_t j1 = has2 ? j + 1 : j;
+    const float uj1 = u[j1], y0j1 = y0[j1], y1j1 = y1[j1];
+
+    float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      d0 += a0[q].x * wv[q].x;
+      d0 += a0[q].y * wv[q].y;
+      d0 += a0[q].z * wv[q].z;
+      d0 += a0[q].w * wv[q].w;
+      d1 += a1[q].x * wv[q].x;
+      d1 += a1[q].y * wv[q].y;
+      d1 += a1[q].z * wv[q].z;
+      d1 += a1[q].w * wv[q].w;
+    }
+    d0 = WaveSumF(d0);
+    d1 = WaveSumF(d1);
+    if (lane == 0) {
+      red[par][wave][0] = d0;
+      red[par][wave][1] = d1;
+    }
+    __syncthreads();
+    d0 = ((red[par][0][0] + red[par][1][0]) + red[par][2][0]) + red[par][3][0];
+    d1 = ((red[par][0][1] + red[par][1][1]) + red[par][2][1]) + red[par][3][1];
+
+    float nx0, nx1, ny0, ny1, nu;
+    const float v0n0 = ChainOne(d0, c, uj0, y0j0, y1j0, &nx0, &nx1, &ny0, &ny1, &nu);
+    if (tid == 0) {
+      y1prev[j] = y1j0;
+      x0[j] = nx0;
+      x1[j] = nx1;
+      y0[j] = ny0;
+      y1[j] = ny1;
+      u[j] = nu;
+    }
+    float v0n1 = 0.0f;
+    if (has2) {
+      v0n1 = ChainOne(d1, c, uj1, y0j1, y1j1, &nx0, &nx1, &ny0, &ny1, &nu);
+      if (tid == 0) {
+        y1prev[j + 1] = y1j1;
+        x0[j + 1] = nx0;
+        x1[j + 1] = nx1;
+        y0[j + 1] = ny0;
+        y1[j + 1] = ny1;
+        u[j + 1] = nu;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      tp[q].x += a0[q].x * v0n0;
+      tp[q].y += a0[q].y * v0n0;
+      tp[q].z += a0[q].z * v0n0;
+      tp[q].w += a0[q].w * v0n0;
+      tp[q].x += a1[q].x * v0n1;
+      tp[q].y += a1[q].y * v0n1;
+      tp[q].z += a1[q].z * v0n1;
+      tp[q].w += a1[q].w * v0n1;
+    }
+  }
+  float* out = tpart + static_cast<int64_t>(blockIdx.x) * m;
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    if (row[q] < m) *reinterpret_cast<float4*>(out + row[q]) = tp[q];
+}
+
+template <int NR>
+void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, const float* w,
+                 const FusedScalars& c, float* u, float* x0, float* x1, float* y0, float* y1,
+                 float* y1prev, float* tpart) {
+  hipLaunchKernelGGL(LassoFusedKernel<NR>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), m,
+                     n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart);
+}
+
+}  // namespace
+
+bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda) {
+  return A.dt == F32 && m >= 4 && m % 4 == 0 && lda % 4 == 0 && m <= 10 * 1024 && n >= 1 &&
+         (reinterpret_cast<uintptr_t>(A.data()) % 16 == 0);
+}
+
+int LassoFusedGrid(int64_t n) {
+  int64_t npairs = (n + 1) / 2;
+  int64_t g = 512;  // 2 workgroups per CU
+  if (g > npairs) g = npairs;
+  return static_cast<int>(g < 1 ? 1 : g);
+}
+
+void LassoFusedPass(const LassoFusedArgs& a) {
+  EPS_CHECK(LassoFusedSupported(a.m, a.n, a.A, a.lda));
+  EPS_CHECK(a.w.n == a.m && a.w.dt == F32);
+  for (const DVec* v : {&a.u, &a.x0, &a.x1, &a.y0, &a.y1, &a.y1prev})
+    EPS_CHECK(v->n == a.n && v->dt == F32);
+  const int grid = LassoFusedGrid(a.n);
+  EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == F32);
+  EPS_CHECK(reinterpret_cast<uintptr_t>(a.w.data()) % 16 == 0 &&
+            reinterpret_cast<uintptr_t>(a.tpart.data()) % 16 == 0);
+  FusedScalars c;
+  c.kappa = static_cast<float>(a.kappa);
+  c.Bs = static_cast<float>(a.Bs);
+  c.Cs = static_cast<float>(a.Cs);
+  c.a1 = static_cast<float>(a.a1);
+  c.lam = static_cast<float>(a.lam);
+  c.alpha = static_cast<float>(a.sz_alpha);
+  c.beta = static_cast<float>(a.sz_beta);
+  c.M = static_cast<float>(a.sz_M);
+  ProfScope prof("lasso_fused", a.m, a.n);
+  const int64_t need = (a.m + 1023) / 1024;
+#define EPS_FUSED_CASE(NRV)                                                                      \
+  LaunchFused<NRV>(grid, a.m, a.n, a.A.as<float>(), a.lda, a.w.as<float>(), c, a.u.as<float>(), \
+                   a.x0.as<float>(), a.x1.as<float>(), a.y0.as<float>(), a.y1.as<float>(),      \
+                   a.y1prev.as<float>(), a.tpart.as<float>())
+  if (need <= 1) EPS_FUSED_CASE(1);
+  else if (need <= 2) EPS_FUSED_CASE(2);
+  else if (need <= 4) EPS_FUSED_CASE(4);
+  else if (need <= 8) EPS_FUSED_CASE(8);
+  else EPS_FUSED_CASE(10);
+#undef EPS_FUSED_CASE
+}
+
+}  // namespace k
+}  // namespace eps

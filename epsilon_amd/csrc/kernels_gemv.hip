@@ -110,15 +110,39 @@ __global__ __launch_bounds__(kBlock) void GemvNKernel(int64_t rows, int64_t cols
   }
 }
 
+// y[r] = alpha * sum_k partial[k][r] + beta*y[r].  64 rows per workgroup, the splits are dealt
+// to the 4 wavefronts and summed in a FIXED order (k ascending inside a wave, then wave 0..3),
+// so the result is deterministic; loads are independent and unrolled so that many are in flight.
 template <class T>
 __global__ __launch_bounds__(kBlock) void GemvNReduceKernel(int64_t rows, int nsplit,
                                                             const T* __restrict__ partial,
                                                             T alpha, T beta, T* y) {
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-  if (r >= rows) return;
+  __shared__ T part[kBlock / 64][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * 64 + lane;
   T s = T(0);
-  for (int k = 0; k < nsplit; ++k) s += partial[static_cast<int64_t>(k) * rows + r];
-  y[r] = (beta == T(0)) ? alpha * s : alpha * s + beta * y[r];
+  if (r < rows) {
+    const int per = (nsplit + 3) / 4;
+    const int k0 = wave * per;
+    int k1 = k0 + per;
+    if (k1 > nsplit) k1 = nsplit;
+    const T* p = partial + r;
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      T v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[static_cast<int64_t>(k + u) * rows];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < k1; ++k) s += p[static_cast<int64_t>(k) * rows];
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && r < rows) {
+    const T t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    y[r] = (beta == T(0)) ? alpha * t : alpha * t + beta * y[r];
+  }
 }
 
 template <class T>
@@ -153,7 +177,7 @@ void LaunchGemvN(int64_t rows, int64_t cols, double alpha, const T* A, int64_t l
                        T(alpha), T(beta), y, partial, cps);
   }
   if (nsplit > 1) {
-    hipLaunchKernelGGL(GemvNReduceKernel<T>, dim3(static_cast<unsigned>((rows + kBlock - 1) / kBlock)),
+    hipLaunchKernelGGL(GemvNReduceKernel<T>, dim3(static_cast<unsigned>((rows + 63) / 64)),
                        dim3(kBlock), 0, s, rows, static_cast<int>(nsplit), partial, T(alpha),
                        T(beta), y);
   }
@@ -238,12 +262,89 @@ __global__ __launch_bounds__(kBlock) void GemvTKernel(int64_t rows, int64_t cols
   }
 }
 
+// GemvT, wide form (the hot one): the workgroup owns 8 columns per pass and ALL rows; a thread
+// owns rows {V*tid + V*256*q}, keeps one partial dot product per column in registers and issues
+// the 8 column loads (16 B each) back to back before any use, so 32 KiB per workgroup are in
+// flight; x sits in LDS.  The 8 partials are reduced wave-wise by shuffles, across the 4
+// wavefronts through LDS, in a fixed order.
+constexpr int kT2Cols = 8;
+
+template <class T, int V>
+__global__ __launch_bounds__(kBlock) void GemvT2Kernel(int64_t rows, int64_t cols,
+                                                       const T* __restrict__ A, int64_t lda,
+                                                       const T* __restrict__ x, T alpha, T beta,
+                                                       T* y) {
+  constexpr int RC = kTLdsBytes / sizeof(T);
+  __shared__ __attribute__((aligned(16))) T xs[RC];
+  __shared__ T red[kBlock / 64][kT2Cols];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t i = threadIdx.x; i < rows; i += kBlock) xs[i] = x[i];  // rows <= RC (launcher)
+  __syncthreads();
+  const int64_t npass = (cols + kT2Cols - 1) / kT2Cols;
+  const int64_t nvec = rows / V;  // rows % V == 0 (launcher)
+  for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    const int64_t j0 = pass * kT2Cols;
+    T acc[kT2Cols];
+#pragma unroll
+    for (int c = 0; c < kT2Cols; ++c) acc[c] = T(0);
+    const T* Ap = A + j0 * lda;
+    if (j0 + kT2Cols <= cols) {
+      for (int64_t p = threadIdx.x; p < nvec; p += kBlock) {
+        T a[kT2Cols][V];
+#pragma unroll
+        for (int c = 0; c < kT2Cols; ++c) Ld<T, V>::load(a[c], Ap + c * lda + p * V);
+        T xv[V];
+        Ld<T, V>::load(xv, xs + p * V);
+#pragma unroll
+        for (int c = 0; c < kT2Cols; ++c)
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[c] += a[c][v] * xv[v];
+      }
+    } else {
+      for (int64_t p = threadIdx.x; p < nvec; p += kBlock) {
+        T xv[V];
+        Ld<T, V>::load(xv, xs + p * V);
+#pragma unroll
+        for (int c = 0; c < kT2Cols; ++c) {
+          if (j0 + c < cols) {
+            T a[V];
+            Ld<T, V>::load(a, Ap + c * lda + p * V);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[c] += a[v] * xv[v];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kT2Cols; ++c) {
+      const T sum = WaveSumT(acc[c]);
+      if (lane == 0) red[wave][c] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < kT2Cols && j0 + threadIdx.x < cols) {
+      const int c = threadIdx.x;
+      const T t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+      const int64_t j = j0 + c;
+      y[j] = (beta == T(0)) ? alpha * t : alpha * t + beta * y[j];
+    }
+    __syncthreads();
+  }
+}
+
 template <class T>
 void LaunchGemvT(int64_t rows, int64_t cols, double alpha, const T* A, int64_t lda, const T* x,
                  double beta, T* y) {
   hipStream_t s = Runtime::Get().stream();
   constexpr int VV = VT<T>::V;
   const bool vec = (reinterpret_cast<uintptr_t>(A) % 16 == 0) && (lda % VV == 0);
+  constexpr int64_t RC = kTLdsBytes / sizeof(T);
+  if (vec && rows % VV == 0 && rows <= RC && rows >= 256 * VV) {
+    int64_t npass = (cols + kT2Cols - 1) / kT2Cols;
+    int64_t grid = npass < 1024 ? npass : 1024;
+    hipLaunchKernelGGL((GemvT2Kernel<T, VV>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                       s, rows, cols, A, lda, x, T(alpha), T(beta), y);
+    return;
+  }
   const int64_t cols_per_pass = (kBlock / 64) * kTCols;
   int64_t npass = (cols + cols_per_pass - 1) / cols_per_pass;
   int64_t grid = npass < 1024 ? npass : 1024;
@@ -258,6 +359,22 @@ void LaunchGemvT(int64_t rows, int64_t cols, double alpha, const T* A, int64_t l
 }
 
 }  // namespace
+
+void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
+                    const DVec& y) {
+  EPS_CHECK(partial.dt == y.dt && y.n == rows && partial.n >= static_cast<int64_t>(nparts) * rows);
+  if (rows == 0) return;
+  hipStream_t s = Runtime::Get().stream();
+  ProfScope prof("reduce_partials", rows, nparts);
+  const unsigned grid = static_cast<unsigned>((rows + 63) / 64);
+  if (y.dt == F32)
+    hipLaunchKernelGGL(GemvNReduceKernel<float>, dim3(grid), dim3(kBlock), 0, s, rows, nparts,
+                       partial.as<float>(), static_cast<float>(alpha), static_cast<float>(beta),
+                       y.as<float>());
+  else
+    hipLaunchKernelGGL(GemvNReduceKernel<double>, dim3(grid), dim3(kBlock), 0, s, rows, nparts,
+                       partial.as<double>(), alpha, beta, y.as<double>());
+}
 
 void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, int64_t lda,
           const DVec& x, double beta, const DVec& y) {

@@ -156,6 +156,25 @@ BlockVector VectorProx::Apply(const BlockVector& v) {  // vector_prox.cc:140-183
   return r;
 }
 
+bool VectorProx::ScalarForm(std::string* var_key, std::string* constraint_key, double* Bs,
+                            double* Cs, double* lam) const {
+  if (input_.elementwise_ || !D_.data().empty() || !g_.data().empty()) return false;
+  if (B_.data().size() != 1 || B_.data().begin()->second.size() != 1) return false;
+  if (C_.data().size() != 1 || C_.data().begin()->second.size() != 1) return false;
+  const auto& bcol = *B_.data().begin();  // (arg:0, constraint)
+  const auto& ccol = *C_.data().begin();  // (var, arg:0)
+  const LinearMap& Bm = bcol.second.begin()->second;
+  const LinearMap& Cm = ccol.second.begin()->second;
+  if (Bm.impl().type() != SCALAR_MATRIX || Cm.impl().type() != SCALAR_MATRIX) return false;
+  if (bcol.second.begin()->first != ccol.first) return false;  // both through arg:0
+  *constraint_key = bcol.first;
+  *var_key = ccol.second.begin()->first;
+  *Bs = GetScalar(Bm);
+  *Cs = GetScalar(Cm);
+  *lam = input_.lambda_;
+  return true;
+}
+
 // ---- ScaledZoneProx: NORM_1, SUM_DEADZONE, SUM_HINGE, SUM_QUANTILE -----------------------------------
 // reference prox/scaled_zone.cc:6-121
 
@@ -231,6 +250,16 @@ class ScaledZoneProx final : public VectorProx {
     }
     k::ScaledZone(x, v, a);
     output->set_value(0, x);
+  }
+
+ public:
+  bool DescribeScaledZone(ScaledZoneDesc* d) const override {
+    if (alpha_.is_vec || beta_.is_vec || has_axis_) return false;
+    if (!ScalarForm(&d->var_key, &d->constraint_key, &d->Bs, &d->Cs, &d->lam)) return false;
+    d->alpha = alpha_.value;
+    d->beta = beta_.value;
+    d->M = M_;
+    return true;
   }
 
  private:
@@ -311,6 +340,36 @@ class SumSquareProx final : public ProxOperator {
   }
   BlockVector Apply(const BlockVector& v) override {
     return chol_.Solve(b_ + v).Select(var_keys_);
+  }
+
+  // Pattern of the compiled lasso: elimination order [constraint, var, arg],
+  // L(var, constraint) = -1, Dinv(constraint) = -1, Dinv(var) = 1, L(arg, var) and Dinv(arg)
+  // dense.  Then Solve(b_ + v)[var] = v_c + kappa * A^T (Dinv_arg (rhs_arg + kappa * A v_c)).
+  bool DescribeLeastSquares(LeastSquaresDesc* d) const override {
+    const std::vector<std::string>& p = chol_.order();
+    if (p.size() != 3 || var_keys_.size() != 1) return false;
+    const std::string &ck = p[0], &vk = p[1], &ak = p[2];
+    if (vk != *var_keys_.begin()) return false;
+    const BlockMatrix& L = chol_.L();
+    const BlockMatrix& Di = chol_.D_inv();
+    auto is_scalar = [](const LinearMap& m, double a) {
+      return m.impl().type() == SCALAR_MATRIX && GetScalar(m) == a;
+    };
+    if (!L.has_key(vk, ck) || !L.has_key(ak, vk) || L.has_key(ak, ck)) return false;
+    if (!Di.has_key(ck, ck) || !Di.has_key(vk, vk) || !Di.has_key(ak, ak)) return false;
+    if (!is_scalar(L(vk, ck), -1.0) || !is_scalar(Di(ck, ck), -1.0) || !is_scalar(Di(vk, vk), 1.0))
+      return false;
+    if (L(ak, vk).impl().type() != DENSE_MATRIX || Di(ak, ak).impl().type() != DENSE_MATRIX)
+      return false;
+    for (const auto& kv : b_.data())
+      if (kv.first != ak) return false;
+    d->constraint_key = ck;
+    d->var_key = vk;
+    d->arg_key = ak;
+    d->L_arg_var = std::static_pointer_cast<const DenseMatrixImpl>(L(ak, vk).ptr());
+    d->Dinv_arg = std::static_pointer_cast<const DenseMatrixImpl>(Di(ak, ak).ptr());
+    if (b_.has_key(ak)) d->rhs_arg = b_(ak);
+    return true;
   }
 
  private:

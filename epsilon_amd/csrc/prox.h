@@ -34,11 +34,27 @@ class ProxOperatorArg {  // reference prox/prox.h:11-35
   const AffineOperator& A_;
 };
 
+// What the sweep fuser (admm.cc) needs to know about an operator to replace its Apply by a
+// fused kernel; an operator that cannot be described this way keeps the generic path.
+struct LeastSquaresDesc {  // SumSquareProx after block elimination [constraint, variable, arg]
+  std::string var_key, arg_key, constraint_key;
+  std::shared_ptr<const DenseMatrixImpl> L_arg_var;  // L(arg, var): lazily scaled data matrix
+  std::shared_ptr<const DenseMatrixImpl> Dinv_arg;   // cached explicit inverse (with its sign)
+  DVec rhs_arg;                                      // constant part of the rhs on the arg row
+};
+struct ScaledZoneDesc {  // ScaledZoneProx with scalar H, A and uniform parameters
+  std::string var_key, constraint_key;
+  double Bs = 0, Cs = 0;  // v' = Bs*v ; x = Cs*x'
+  double lam = 0, alpha = 1, beta = 1, M = 0;
+};
+
 class ProxOperator {  // reference prox/prox.h:37-43
  public:
   virtual ~ProxOperator() {}
   virtual void Init(const ProxOperatorArg& arg) {}
   virtual BlockVector Apply(const BlockVector& v) = 0;
+  virtual bool DescribeLeastSquares(LeastSquaresDesc* d) const { return false; }
+  virtual bool DescribeScaledZone(ScaledZoneDesc* d) const { return false; }
 };
 
 std::unique_ptr<ProxOperator> CreateProxOperator(int type, bool epigraph);
@@ -100,6 +116,13 @@ class VectorProx : public ProxOperator {
  private:
   bool InitScalar(const ProxOperatorArg& arg);
   bool InitDiagonal(const ProxOperatorArg& arg);
+
+ protected:
+  // For DescribeScaledZone: true iff B_, C_ are single scalar blocks, no offset, scalar lambda.
+  bool ScalarForm(std::string* var_key, std::string* constraint_key, double* Bs, double* Cs,
+                  double* lam) const;
+
+ private:
   BlockMatrix B_, C_, D_;
   BlockVector g_;
   VectorProxInput input_;

@@ -161,6 +161,15 @@ int eps_linear_map_binary(char op, const void* a, size_t a_len, int ta, const vo
 /* Inverse of a serialized map (reference LinearMapImpl::Inverse), dense values out. */
 int eps_linear_map_inverse(const void* linear_map, size_t len, const eps_blob* data,
                            size_t ndata, double* dense, size_t dense_capacity);
+/* Micro-benchmark of the dense mat-vec kernels on device-resident synthetic data: average
+ * milliseconds per launch over `iters` launches (HIP events on the solver stream). */
+int eps_bench_gemv(int trans, int64_t rows, int64_t cols, int iters, double* ms_avg);
+/* Same for C = op(A) op(B) (M x N x K); lower_only = SYRK-style. */
+int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int lower_only,
+                   int iters, double* ms_avg);
+/* SPD inverse of an n x n synthetic matrix. */
+int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg);
+
 /* Exact 1-D total-variation prox of v (n float64) with weight lam
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
 int eps_tv1d(const double* v, size_t n, double lam, double* x);

@@ -351,3 +351,68 @@ def test_rccl_backend_single_rank(solve_mod):
     r = subprocess.run([sys.executable, os.path.join(here, "rccl_single_rank.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (4100, 4301), (8, 21), (1500, 701)])
+@pytest.mark.parametrize("kind", ["lasso", "deadzone"])
+def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
+    """The one-pass fused sweep (kernels_fused.hip) against the unfused operator path (same
+    library, fused=0) and the oracle: same stopping sweep, same residuals, iterates within fp32
+    rounding of each other."""
+    solve_mod.set_option("dtype", "f32")
+    m, n = shape
+    if kind == "lasso":
+        prob, info = problems.lasso(m, n, seed=5)
+    else:
+        A, b = problems.regression_data(m, n, seed=5)
+        lam = 0.3 * np.abs(A.T.dot(b)).max()
+        x = ir.variable(n, 1, problems.LASSO_COPY)
+        y = ir.variable(n, 1, problems.LASSO_VAR)
+        f0 = ir.prox(ProxFunction.SUM_SQUARE, ir.add(ir.linear_map(ir.dense_matrix(A), x),
+                                                     ir.linear_map(ir.scalar(-1, m), ir.constant(b))))
+        f1 = ir.prox(ProxFunction.SUM_DEADZONE, ir.linear_map(ir.scalar(2.0, n), y), alpha=lam,
+                     scaled_zone_params=wire.ProxScaledZoneParams(m=0.05))
+        prob = ir.Problem([f0, f1], [ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, n), y)))])
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    sb = wire.SolverParams(max_iterations=200).SerializeToString()
+    try:
+        solve_mod.set_option("fused", "1")
+        solve_mod.profile_reset()
+        solve_mod.profile_enable(True)
+        st_f, x_f = solve_mod.solve(pb, [], sb, data)
+        tags = solve_mod.profile_dump()
+        solve_mod.profile_enable(False)
+        solve_mod.set_option("fused", "0")
+        st_g, x_g = solve_mod.solve(pb, [], sb, data)
+    finally:
+        solve_mod.set_option("fused", "1")
+    took_fused = any(t.startswith("lasso_fused") for t in tags)
+    # fat problems eliminate to the m x m Gram and match the fused pattern; a tall one (m > n)
+    # eliminates the argument row first (n x n Gram) and must stay on the generic path
+    assert took_fused == (m < n), "fused=%s for %dx%d: %s" % (took_fused, m, n, list(tags))
+    st_o, x_o = orc.solve(pb, [], sb, data)
+    sf, sg, so = (wire.SolverStatus.FromString(s) for s in (st_f, st_g, st_o))
+    assert sf.state == sg.state == so.state
+    assert sf.num_iterations == sg.num_iterations == so.num_iterations
+    for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
+        np.testing.assert_allclose(getattr(sf.residuals, f), getattr(so.residuals, f), rtol=3e-3, atol=1e-5)
+    for k in x_o:
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_g[k]), rtol=1e-4, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+def test_fused_sweep_sharded(solve_mod, tmp_path):
+    """Fused pass on column slabs with the all-reduce between the pass and the cached-inverse
+    apply (3 ranks sharing this GPU, fp32)."""
+    from tests import mp_util
+    m, n = 40, 101
+    x0, x1, status, parts = mp_util.run_ranks(3, "hip", str(tmp_path), m, n, seed=3,
+                                              env_extra={"EPS_TEST_DTYPE": "f32"})
+    prob, info = problems.lasso(m, n, seed=3)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams().SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    for s, p in zip(status, parts):
+        assert int(p["state"]) == wire.SolverStatus.OPTIMAL and int(s[0]) == S.num_iterations
+    np.testing.assert_allclose(x0, np.frombuffer(x[problems.LASSO_COPY]), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=1e-3, atol=1e-4)

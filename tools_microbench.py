@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the GPU box (not part of the judged bench): prints one line per
+case with ms and the algorithmic rate."""
+import ctypes
+import sys
+
+sys.path.insert(0, ".")
+from epsilon_amd import _solve  # noqa: E402
+
+L = _solve.lib()
+
+
+def gemv(trans, rows, cols, iters=50, dtype="f32"):
+    _solve.set_option("dtype", dtype)
+    ms = ctypes.c_double()
+    _solve._check(L.eps_bench_gemv(ctypes.c_int(trans), ctypes.c_int64(rows), ctypes.c_int64(cols),
+                                   ctypes.c_int(iters), ctypes.byref(ms)))
+    sz = 4 if dtype == "f32" else 8
+    print("gemv_%s %dx%d %s: %.4f ms  %.0f GB/s" % ("t" if trans else "n", rows, cols, dtype, ms.value,
+                                                  rows * cols * sz / ms.value / 1e6), flush=True)
+
+
+def gemm(ta, tb, M, N, K, lower=0, iters=3, dtype="f32"):
+    _solve.set_option("dtype", dtype)
+    ms = ctypes.c_double()
+    _solve._check(L.eps_bench_gemm(ctypes.c_int(ta), ctypes.c_int(tb), ctypes.c_int64(M), ctypes.c_int64(N),
+                                   ctypes.c_int64(K), ctypes.c_int(lower), ctypes.c_int(iters), ctypes.byref(ms)))
+    fl = 2.0 * M * N * K
+    print("gemm %s%s %dx%dx%d lower=%d %s: %.3f ms  %.1f TFLOP/s (GEMM-equivalent)" %
+          ("T" if ta else "N", "T" if tb else "N", M, N, K, lower, dtype, ms.value, fl / ms.value / 1e9), flush=True)
+
+
+def inverse(n, iters=2, dtype="f32"):
+    _solve.set_option("dtype", dtype)
+    ms = ctypes.c_double()
+    _solve._check(L.eps_bench_spd_inverse(ctypes.c_int64(n), ctypes.c_int(iters), ctypes.byref(ms)))
+    print("spd_inverse n=%d %s: %.2f ms" % (n, dtype, ms.value), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["gemv", "gemm", "inverse"]
+    if "gemv" in what:
+        gemv(0, 10000, 50000)
+        gemv(1, 10000, 50000)
+        gemv(0, 10000, 10000)
+        gemv(1, 10000, 10000)
+        gemv(0, 10000, 6272)
+        gemv(1, 10000, 6272)
+    if "gemm" in what:
+        gemm(0, 1, 10000, 10000, 50000, lower=1, iters=2)
+        gemm(0, 1, 4096, 4096, 4096, iters=5)
+        gemm(0, 0, 4096, 4096, 4096, iters=5)
+        gemm(1, 0, 4096, 4096, 4096, iters=5)
+    if "inverse" in what:
+        inverse(10000)
+        inverse(2048)
