@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-time-to-eps", action="store_true")
+    p.add_argument("--force-sharded", action="store_true",
+                   help="rehearsal on one GPU: run the sharded code path (RCCL communicator of "
+                        "size 1) - not a judged configuration")
     return p.parse_args()
 
 
@@ -113,13 +116,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if args.force_sharded and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29653")
+        os.environ["EPSILON_HIP_FORCE_SHARDED"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    elif world > 1:
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d" % args.gpus
 
     m, n = args.m, args.n
     _solve.set_option("dtype", args.dtype)
-    sharded = world > 1
+    sharded = world > 1 or args.force_sharded
     if sharded:
         from epsilon_amd import dist as edist
         cols = edist.column_range(n, rank, world)
@@ -131,7 +139,7 @@ def main():
     pb, data = prob.SerializeToString(), prob.expression_data()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,8 +192,8 @@ def main():
     s.close()
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        _solve.comm_shutdown()
+        dist.destroy_process_group()
         return
 
     sz = 4 if args.dtype == "f32" else 8
@@ -236,8 +244,9 @@ def main():
     })
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(At, b, lam)
-    print(json.dumps(out))
-    if world > 1:
+    print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        _solve.comm_shutdown()
         dist.destroy_process_group()
 
 

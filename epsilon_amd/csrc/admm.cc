@@ -1,5 +1,6 @@
 #include "admm.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -269,10 +270,17 @@ class ProxADMMSolver final : public Solver {
     f.y1 = state(y_[1], ck);
     f.u = state(u_, ck);
     f.y1prev = DVec::Zeros(f.n, dt);
-    f.w = DVec::Zeros(f.m, dt);
     f.p = DVec::Zeros(f.m, dt);
     f.grid = k::LassoFusedGrid(f.n);
     f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
+    {
+      Comm* comm = Runtime::Get().comm();
+      const int G = comm ? comm->size() : 1;
+      f.slab = ((f.m + G - 1) / G + 3) / 4 * 4;
+      f.wpad = DVec::Zeros(f.slab * G, dt);
+      f.wslice = DVec::Zeros(f.slab, dt);
+      f.w = f.wpad.Slice(0, f.m);  // the gathered vector IS w (first m entries)
+    }
     fs_ = f;
     // the generic containers become views of the fused state
     x_[0] = BlockVector();
@@ -306,9 +314,30 @@ class ProxADMMSolver final : public Solver {
       k::ReducePartials(f.m, f.grid, f.tpart, -L.scale(), 0.0, f.p);
     }
     const ShardSpec& sh = ShardSpec::Get();
-    if (sh.active() && sh.IsSharded(f.ls.var_key)) Runtime::Get().comm()->AllReduceSum(f.p);
+    const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
+    if (sharded) Runtime::Get().comm()->AllReduceSum(f.p);
     if (f.ls.rhs_arg.n != 0) k::Axpby(f.p, 1.0, f.ls.rhs_arg, 1.0);
-    f.ls.Dinv_arg->Apply(1.0, f.p, 0.0, f.w);
+    const DenseMatrixImpl& D = *f.ls.Dinv_arg;
+    Comm* comm = Runtime::Get().comm();
+    if (sharded && comm->size() > 1 && !D.trans() && D.rows() == f.m) {
+      // The cached inverse is replicated and symmetric: each rank applies only its slab of rows
+      // (= columns, read contiguously) and the slices are all-gathered, so the m^2 bytes of the
+      // apply are split over the ranks like the data matrix is.
+      const int G = comm->size();
+      const int64_t per = f.slab;  // multiple of 4, G*per >= m
+      const int64_t lo = std::min<int64_t>(f.m, comm->rank() * per);
+      const int64_t cnt = std::min<int64_t>(f.m, lo + per) - lo;
+      DVec mine = f.wslice;
+      if (cnt < per) k::Fill(mine, 0.0);
+      if (cnt > 0) {
+        DVec slab = D.data().Slice(lo * f.m, cnt * f.m);
+        k::Gemv(true, f.m, cnt, D.scale(), slab, f.m, f.p, 0.0, mine.Slice(0, cnt));
+      }
+      comm->AllGather(mine.data(), f.wpad.data(), static_cast<size_t>(per), F32);
+      (void)G;
+    } else {
+      D.Apply(1.0, f.p, 0.0, f.w);
+    }
   }
 
   void FusedSweep() {
@@ -408,7 +437,8 @@ class ProxADMMSolver final : public Solver {
     double a1 = 0;
     int64_t m = 0, n = 0;
     int grid = 0;
-    DVec u, x0, x1, y0, y1, y1prev, w, p, tpart;
+    int64_t slab = 0;  // rows of the cached inverse applied per rank (sharded runs)
+    DVec u, x0, x1, y0, y1, y1prev, w, p, tpart, wpad, wslice;
   };
   bool fused_ = false;
   FusedState fs_;

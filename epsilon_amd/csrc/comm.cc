@@ -35,6 +35,7 @@ struct RcclApi {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, /* ncclUniqueId by value */ Id128, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
@@ -55,9 +56,11 @@ RcclApi& Api() {
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  EPS_CHECK_MSG(api.GetUniqueId && api.CommInitRank && api.AllReduce && api.CommDestroy,
+  EPS_CHECK_MSG(api.GetUniqueId && api.CommInitRank && api.AllReduce && api.AllGather &&
+                    api.CommDestroy,
                 "librccl.so lacks the expected symbols");
   return api;
 }
@@ -89,6 +92,12 @@ class RcclComm final : public Comm {
                               comm_, Runtime::Get().stream()),
               "ncclAllReduce");
   }
+  void AllGather(const void* send, void* recv, size_t count, DType dt) override {
+    if (count == 0) return;
+    CheckNccl(Api().AllGather(send, recv, count, dt == F32 ? kNcclFloat32 : kNcclFloat64, comm_,
+                              Runtime::Get().stream()),
+              "ncclAllGather");
+  }
 
  private:
   int rank_, size_;
@@ -111,6 +120,16 @@ class HostCallbackComm final : public Comm {
     fn_(host_.data(), count, dt == F32 ? 0 : 1, ctx_);
     EPS_HIP(hipMemcpyAsync(p, host_.data(), bytes, hipMemcpyHostToDevice, s));
     EPS_HIP(hipStreamSynchronize(s));
+  }
+  void AllGather(const void* send, void* recv, size_t count, DType dt) override {
+    // test backend: zero everything but the own slice, then sum
+    if (count == 0) return;
+    const size_t es = DTypeSize(dt);
+    hipStream_t s = Runtime::Get().stream();
+    EPS_HIP(hipMemsetAsync(recv, 0, count * es * size_, s));
+    EPS_HIP(hipMemcpyAsync(static_cast<char*>(recv) + rank_ * count * es, send, count * es,
+                           hipMemcpyDeviceToDevice, s));
+    AllReduceSum(recv, count * size_, dt);
   }
 
  private:

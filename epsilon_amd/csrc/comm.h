@@ -28,6 +28,8 @@ class Comm {
   // In-place sum over ranks, ordered on the runtime stream.
   virtual void AllReduceSum(void* dev_ptr, size_t count, DType dt) = 0;
   void AllReduceSum(const DVec& v) { AllReduceSum(v.data(), static_cast<size_t>(v.n), v.dt); }
+  // recv[r*count .. (r+1)*count) = rank r's send[0..count); recv may not alias send.
+  virtual void AllGather(const void* send_dev, void* recv_dev, size_t count, DType dt) = 0;
 };
 
 typedef void (*HostAllReduceFn)(void* host_buf, size_t count, int dtype, void* ctx);
