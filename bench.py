@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-time-to-eps", action="store_true")
+    p.add_argument("--no-profile", action="store_true",
+                   help="diagnostic: no HIP-event kernel timers in the timed region (no roofline)")
+    p.add_argument("--profile-all", action="store_true", help="time every tagged kernel")
     p.add_argument("--force-sharded", action="store_true",
                    help="rehearsal on one GPU: run the sharded code path (RCCL communicator of "
                         "size 1) - not a judged configuration")
@@ -173,7 +176,11 @@ def main():
     params = wire.SolverParams(max_iterations=10 ** 9, ignore_stopping_criteria=True)
     s = new_solver(params)
     s.init()
-    _solve.profile_enable(True)
+    # live HIP-event timers only around the dominant kernel (each bracket costs ~1 us of stream
+    # time; timing every small kernel would tax the sweep being measured by ~7 %)
+    _solve.set_option("profile_filter",
+                      "" if args.profile_all else "lasso_fused,gemv_n:%dx%d" % (m, At.shape[0]))
+    _solve.profile_enable(not args.no_profile)
     s.run(args.warmup)
     _solve.profile_reset()
     barrier()

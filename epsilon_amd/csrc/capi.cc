@@ -110,6 +110,8 @@ int eps_set_option(const char* key, const char* value) {
       setenv("EPSILON_HIP_DEVICE", value, 1);
     } else if (std::strcmp(key, "gemm") == 0) {
       setenv("EPSILON_HIP_GEMM", value, 1);
+    } else if (std::strcmp(key, "profile_filter") == 0) {
+      Runtime::Get().set_prof_filter(value);
     } else if (std::strcmp(key, "fused") == 0) {
       setenv("EPSILON_HIP_FUSED", value, 1);
     } else {

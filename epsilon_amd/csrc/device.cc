@@ -163,9 +163,22 @@ void Runtime::ProfReset() {
   prof_totals_.clear();
 }
 
+bool Runtime::ProfWanted(const char* name) const {
+  if (prof_filter_.empty()) return true;
+  size_t pos = 0;
+  const std::string n(name);
+  while (pos <= prof_filter_.size()) {
+    size_t end = prof_filter_.find(',', pos);
+    if (end == std::string::npos) end = prof_filter_.size();
+    if (end > pos && n.compare(0, end - pos, prof_filter_, pos, end - pos) == 0) return true;
+    pos = end + 1;
+  }
+  return false;
+}
+
 ProfScope::ProfScope(const char* name, int64_t a, int64_t b) {
   Runtime& rt = Runtime::Get();
-  on = rt.profiling();
+  on = rt.profiling() && rt.ProfWanted(name);
   if (!on) return;
   std::string tag = name;
   if (a >= 0) tag += ":" + std::to_string(a);

@@ -63,6 +63,9 @@ class Runtime {
   // ---- live kernel timing (HIP events on this stream; off unless eps_profile_enable) -------
   bool profiling() const { return profiling_; }
   void set_profiling(bool on) { profiling_ = on; }
+  // only tags starting with one of these comma-separated prefixes are timed (empty: all)
+  void set_prof_filter(const std::string& f) { prof_filter_ = f; }
+  bool ProfWanted(const char* name) const;
   size_t ProfBegin(const std::string& tag);  // returns the entry index for ProfEnd
   void ProfEnd(size_t index);
   void ProfCollect();  // synchronises, folds finished event pairs into the totals
@@ -89,6 +92,7 @@ class Runtime {
   int slots_used_ = 0;
   Comm* comm_ = nullptr;
   bool profiling_ = false;
+  std::string prof_filter_;
   struct ProfPending { std::string tag; hipEvent_t a, b; };
   std::vector<ProfPending> prof_pending_;
   int prof_open_ = 0;

@@ -204,13 +204,172 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32Kernel(
   }
 }
 
-int GemmMode() {  // 0 auto, 1 generic, 2 mfma
+// ------------------------------------------------------------------------------------------
+// f32 MFMA kernel, pipelined form (16-byte aligned operands): same tile / wave geometry, but
+//   * every global load is 16 B per lane (4 per thread per operand per k-slab) and is issued
+//     for slab k+1 BEFORE the MFMAs of slab k, so HBM/L2 latency hides under the matrix work;
+//   * operands contiguous along the output index land in LDS with ds_write_b128 (row stride
+//     132 floats), operands contiguous along k are transposed through scalar LDS writes with
+//     row stride 129 (conflict-free in both cases);
+//   * bounds checks only on edge tiles / the last k-slab.
+// ------------------------------------------------------------------------------------------
+template <bool CR> struct StageCfg { static constexpr int LD = CR ? 132 : 129; };
+
+template <bool CR>
+__device__ inline void LoadSlab(float4 (&r)[4], const float* __restrict__ X, int64_t ld,
+                                int64_t r0, int64_t k0, int64_t R, int64_t K, bool interior) {
+  const int t = threadIdx.x;
+  if (CR) {
+    const int rr4 = (t & 31) * 4;
+    const int kb = t >> 5;  // 0..7
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t gk = k0 + kb + 8 * p, gr = r0 + rr4;
+      const float* src = X + gr + gk * ld;
+      if (interior) {
+        r[p] = *reinterpret_cast<const float4*>(src);
+      } else {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (gk < K) {
+          if (gr + 0 < R) v.x = src[0];
+          if (gr + 1 < R) v.y = src[1];
+          if (gr + 2 < R) v.z = src[2];
+          if (gr + 3 < R) v.w = src[3];
+        }
+        r[p] = v;
+      }
+    }
+  } else {
+    const int kk4 = (t & 7) * 4;
+    const int rb = t >> 3;  // 0..31
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t gk = k0 + kk4, gr = r0 + rb + 32 * p;
+      const float* src = X + gk + gr * ld;
+      if (interior) {
+        r[p] = *reinterpret_cast<const float4*>(src);
+      } else {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (gr < R) {
+          if (gk + 0 < K) v.x = src[0];
+          if (gk + 1 < K) v.y = src[1];
+          if (gk + 2 < K) v.z = src[2];
+          if (gk + 3 < K) v.w = src[3];
+        }
+        r[p] = v;
+      }
+    }
+  }
+}
+
+template <bool CR>
+__device__ inline void StoreSlab(float* __restrict__ S, const float4 (&r)[4]) {
+  const int t = threadIdx.x;
+  constexpr int LD = StageCfg<CR>::LD;
+  if (CR) {
+    const int rr4 = (t & 31) * 4;
+    const int kb = t >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(S + (kb + 8 * p) * LD + rr4) = r[p];
+  } else {
+    const int kk4 = (t & 7) * 4;
+    const int rb = t >> 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rr = rb + 32 * p;
+      S[(kk4 + 0) * LD + rr] = r[p].x;
+      S[(kk4 + 1) * LD + rr] = r[p].y;
+      S[(kk4 + 2) * LD + rr] = r[p].z;
+      S[(kk4 + 3) * LD + rr] = r[p].w;
+    }
+  }
+}
+
+// CA: op(A) contiguous along i (A not transposed); CB: op(B) contiguous along j (B transposed)
+template <bool CA, bool CB>
+__global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
+    int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
+    const float* __restrict__ B, int64_t ldb, float beta, float* C, int64_t ldc,
+    int lower_only) {
+  constexpr int LDA = StageCfg<CA>::LD, LDB = StageCfg<CB>::LD;
+  __shared__ __attribute__((aligned(16))) float As[MK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[MK * LDB];
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * MT;
+  if (lower_only && i0 + MT <= j0) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave & 1, wj = wave >> 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool in_i = i0 + MT <= M, in_j = j0 + MT <= N;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float4 ra[4], rb[4];
+  const int64_t nk = (K + MK - 1) / MK;
+  {
+    const bool in_k = MK <= K;
+    LoadSlab<CA>(ra, A, lda, i0, 0, M, K, in_i && in_k);
+    LoadSlab<CB>(rb, B, ldb, j0, 0, N, K, in_j && in_k);
+  }
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    StoreSlab<CA>(As, ra);
+    StoreSlab<CB>(Bs, rb);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int64_t k1 = (kt + 1) * MK;
+      const bool in_k = k1 + MK <= K;
+      LoadSlab<CA>(ra, A, lda, i0, k1, M, K, in_i && in_k);
+      LoadSlab<CB>(rb, B, ldb, j0, k1, N, K, in_j && in_k);
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < MK; kk += 2) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = As[(kk + lh) * LDA + wi * 64 + a * 32 + l31];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = Bs[(kk + lh) * LDB + wj * 64 + b * 32 + l31];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[b], av[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int64_t i = i0 + wi * 64 + a * 32 + l31;
+    if (i >= M) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (j >= N) continue;
+        float* c = C + i + j * ldc;
+        const float v = alpha * acc[a][b][r];
+        *c = (beta == 0.0f) ? v : v + beta * (*c);
+      }
+    }
+  }
+}
+
+int GemmMode() {  // 0 auto, 1 generic, 2 mfma, 3 mfma without the pipelined kernel
   static int mode = -1;
   if (mode < 0) {
     const char* e = std::getenv("EPSILON_HIP_GEMM");
     mode = 0;
     if (e && std::strcmp(e, "generic") == 0) mode = 1;
     if (e && std::strcmp(e, "mfma") == 0) mode = 2;
+    if (e && std::strcmp(e, "mfma_simple") == 0) mode = 3;
   }
   return mode;
 }
@@ -233,9 +392,25 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
   ProfScope prof(lower_only ? "syrk" : "gemm", M * N, K);
   const int mode = GemmMode();
   const bool use_mfma = A.dt == F32 && mode != 1 &&
-                        (mode == 2 || (M >= 64 && N >= 64 && K >= 32));
+                        (mode >= 2 || (M >= 64 && N >= 64 && K >= 32));
   if (use_mfma) {
     dim3 grid(static_cast<unsigned>((M + MT - 1) / MT), static_cast<unsigned>((N + MT - 1) / MT));
+    const bool aligned = lda % 4 == 0 && ldb % 4 == 0 &&
+                         reinterpret_cast<uintptr_t>(A.data()) % 16 == 0 &&
+                         reinterpret_cast<uintptr_t>(B.data()) % 16 == 0;
+    if (aligned && mode != 3) {
+      const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
+      const int lo = lower_only ? 1 : 0;
+#define EPS_PIPE(CA, CB)                                                                       \
+  hipLaunchKernelGGL((GemmMfmaF32PipeKernel<CA, CB>), grid, dim3(kBlock), 0, s, M, N, K, al,    \
+                     A.as<float>(), lda, B.as<float>(), ldb, be, C.as<float>(), ldc, lo)
+      if (!transA && transB) EPS_PIPE(true, true);
+      else if (!transA && !transB) EPS_PIPE(true, false);
+      else if (transA && transB) EPS_PIPE(false, true);
+      else EPS_PIPE(false, false);
+#undef EPS_PIPE
+      return;
+    }
     hipLaunchKernelGGL(GemmMfmaF32Kernel, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
                        transB ? 1 : 0, M, N, K, static_cast<float>(alpha), A.as<float>(), lda,
                        B.as<float>(), ldb, static_cast<float>(beta), C.as<float>(), ldc,
