@@ -95,6 +95,14 @@ void MaxZero(const DVec& x, const DVec& v);
 void Norm2Shrink(const DVec& x, const DVec& v, double lam, const double* normsq);
 // x = soft-threshold of singular values etc. is composed from ScaledZone.
 
+// ---- K11: SVD for the orthogonally-invariant proxes (reference prox/ortho_invariant.cc) ------
+// One-sided Jacobi on W (m x n, ld = m): on return W = U*Sigma (orthogonal columns) and the
+// input equals W V^T; V (n x n) is overwritten.  Returns the number of sweeps used.
+int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40);
+void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma);
+// W[:, j] *= xt[j] / sigma[j]   (0 where sigma[j] == 0, as ortho_invariant.cc:44-49)
+void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt);
+
 // reference prox/total_variation_1d.cc:21 (glmgen tf_dp): exact 1-D TV prox
 void Tv1d(const DVec& x, const DVec& v, double lam);
 

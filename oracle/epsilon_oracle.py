@@ -1087,7 +1087,10 @@ class OrthoInvariantProx(VectorProx):  # prox/ortho_invariant.cc:7-116 (non-epig
         self.eigen_prox = None
 
     def _init_eigen_prox(self, lam):  # :76-98
-        n = min(self.m_, self.n_)
+        # The reference sizes the nested prox with min(m, n) (:77) but feeds it the n
+        # eigenvalues of Y^T Y (:36-50); for m < n its parameter vectors are then indexed out of
+        # bounds (undefined behaviour).  The well-defined reading - n entries - is used here.
+        n = self.n_
         self.alpha_ = 1.0 / math.sqrt(lam)
         f = ProxFunction(prox_function_type=self.eigen_prox_type, alpha=1.0,
                          arg_size=[wire.Size(dim=[n, 1])])

@@ -416,3 +416,32 @@ def test_fused_sweep_sharded(solve_mod, tmp_path):
         assert int(p["state"]) == wire.SolverStatus.OPTIMAL and int(s[0]) == S.num_iterations
     np.testing.assert_allclose(x0, np.frombuffer(x[problems.LASSO_COPY]), rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (12, 7), (7, 12), (40, 25), (1, 5)])
+def test_nuclear_norm_prox(solve_mod, dtype, shape):
+    """NORM_NUCLEAR (reference prox_test.py:190; prox/ortho_invariant.cc): one-sided Jacobi SVD
+    on the device vs the oracle's eig(Y^T Y) restatement and vs numpy's SVD."""
+    m, n = shape
+    rng = np.random.RandomState(m * 100 + n)
+    V = rng.randn(m, n)
+    lam = 0.4
+    X = ir.variable(m, n, "var:X")
+    expr = ir.prox(ProxFunction.NORM_NUCLEAR, X)
+    tol = dict(rtol=1e-7, atol=1e-8) if dtype == "f64" else dict(rtol=2e-4, atol=2e-5)
+    got = run_prox(solve_mod, expr, lam, {"var:X": V.reshape(-1, order="F")}, tol)
+    U, s, Vt = np.linalg.svd(V, full_matrices=False)
+    want = (U * np.maximum(s - lam, 0)) @ Vt
+    np.testing.assert_allclose(np.frombuffer(got["var:X"]).reshape((m, n), order="F"), want, **tol)
+
+
+@pytest.mark.parametrize("n", [10, 24])
+def test_robust_pca_problem(solve_mod, dtype, n):
+    """BASELINE.json configs[4] shape (robust PCA: NORM_NUCLEAR + NORM_1, constraint with a
+    constant) at test size, iterate parity with the oracle."""
+    prob, info = problems.robust_pca(n, r=2, seed=0)
+    sg, xg, so, xo = solve_both(solve_mod, prob, wire.SolverParams(max_iterations=60))
+    assert sg.num_iterations == so.num_iterations and sg.state == so.state
+    tol = dict(rtol=1e-6, atol=1e-7) if dtype == "f64" else dict(rtol=5e-3, atol=5e-3)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
