@@ -105,6 +105,8 @@ void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, con
 
 // reference prox/total_variation_1d.cc:21 (glmgen tf_dp): exact 1-D TV prox
 void Tv1d(const DVec& x, const DVec& v, double lam);
+// the same by Johnson's sequential DP on one lane (cross-check of the parallel kernel)
+void Tv1dSerial(const DVec& x, const DVec& v, double lam);
 
 }  // namespace k
 }  // namespace eps

@@ -196,7 +196,7 @@ void Norm2Shrink(const DVec& x, const DVec& v, double lam, const double* normsq)
                        x.as<double>(), v.as<double>(), x.n, lam, normsq);
 }
 
-void Tv1d(const DVec& x, const DVec& v, double lam) {
+void Tv1dSerial(const DVec& x, const DVec& v, double lam) {
   EPS_CHECK(x.n == v.n && x.dt == v.dt);
   const int64_t n = x.n;
   if (n == 0) return;

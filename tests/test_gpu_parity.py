@@ -445,3 +445,35 @@ def test_robust_pca_problem(solve_mod, dtype, n):
     tol = dict(rtol=1e-6, atol=1e-7) if dtype == "f64" else dict(rtol=5e-3, atol=5e-3)
     for k in xo:
         np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
+
+
+@pytest.mark.parametrize("case", ["noise", "walk", "ties", "steps", "big", "tiny"])
+def test_tv1d_parallel_kernel(solve_mod, dtype, case):
+    """Exact parallel TV-1D prox (level-set divide and conquer, kernels_tv.hip) vs the DP
+    oracle, plus the KKT certificate of SURVEY.md 8(c) on the device result."""
+    from oracle import c_oracle
+    rng = np.random.RandomState(11)
+    if case == "noise":
+        v, lam = rng.randn(5000), 0.7
+    elif case == "walk":
+        v, lam = np.cumsum(rng.randn(20000)) + rng.randn(20000), 25.0
+    elif case == "ties":
+        v, lam = np.round(rng.randn(3000) * 2), 1.0
+    elif case == "steps":
+        v, lam = np.repeat(rng.randn(300), 50) + 0.1 * rng.randn(15000), 3.0
+    elif case == "big":
+        b, lam = problems.tv_1d_data(300000, seed=1)
+        v = b
+    else:
+        v, lam = np.array([0.0, 10.0]), 1.0
+    if dtype == "f32":
+        v = v.astype(np.float32).astype(np.float64)
+    got = solve_mod.tv1d(v, lam)
+    want = c_oracle.tv1d(v, lam)
+    tol = dict(rtol=1e-9, atol=1e-9) if dtype == "f64" else dict(rtol=1e-4, atol=1e-4 * max(1.0, np.abs(v).max()))
+    np.testing.assert_allclose(got, want, **tol)
+    if dtype == "f64":
+        bound, jump, end = orc.tv1d_kkt_violation(got, v, lam)
+        assert bound < 1e-7 and jump < 1e-7 and end < 1e-7
+    if case == "tiny":
+        np.testing.assert_allclose(got, [1.0, 9.0])
