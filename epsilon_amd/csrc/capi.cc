@@ -500,4 +500,17 @@ int eps_tv1d(const double* v, size_t n, double lam, double* x) {
   });
 }
 
+int eps_tv1d_device(const void* v_dev, void* x_dev, size_t n, int kind, double lam, int* levels) {
+  return Guard([&] {
+    EPS_CHECK(v_dev != nullptr && x_dev != nullptr);
+    EPS_CHECK_MSG(kind == EPS_BLOB_DEVICE_F32 || kind == EPS_BLOB_DEVICE_F64, "bad kind");
+    const DType dt = kind == EPS_BLOB_DEVICE_F32 ? F32 : F64;
+    DVec v = DVec::Borrow(const_cast<void*>(v_dev), static_cast<int64_t>(n), dt);
+    DVec x = DVec::Borrow(x_dev, static_cast<int64_t>(n), dt);
+    k::Tv1d(x, v, lam);
+    Runtime::Get().Sync();
+    if (levels) *levels = k::Tv1dLastLevels();
+  });
+}
+
 }  // extern "C"

@@ -105,6 +105,7 @@ void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, con
 
 // reference prox/total_variation_1d.cc:21 (glmgen tf_dp): exact 1-D TV prox
 void Tv1d(const DVec& x, const DVec& v, double lam);
+int Tv1dLastLevels();  // depth of the level-set recursion of the last Tv1d call
 // the same by Johnson's sequential DP on one lane (cross-check of the parallel kernel)
 void Tv1dSerial(const DVec& x, const DVec& v, double lam);
 

@@ -78,19 +78,25 @@ __global__ __launch_bounds__(kBlock) void ScanReduceKernel(Op op, int64_t n,
   if (threadIdx.x == 0) agg[blockIdx.x] = total;
 }
 
-// exclusive scan of the block aggregates, in place, by one workgroup
+// exclusive scan of the block aggregates, in place, by one workgroup: every thread owns a
+// contiguous chunk (sequential reduce, ONE workgroup scan of the 256 chunk totals, sequential
+// write-back), so the number of barriers does not grow with the number of blocks
 template <class Op>
 __global__ __launch_bounds__(kBlock) void ScanAggKernel(int64_t nb, typename Op::S* agg) {
   using S = typename Op::S;
   __shared__ S lds[kBlock];
-  S carry = Op::identity();
-  for (int64_t base = 0; base < nb; base += kBlock) {
-    const int64_t i = base + threadIdx.x;
-    S mine = i < nb ? agg[i] : Op::identity();
-    S total;
-    S excl = BlockExclusive<S, Op>(mine, lds, &total);
-    if (i < nb) agg[i] = Op::combine(carry, excl);
-    carry = Op::combine(carry, total);
+  const int64_t chunk = (nb + kBlock - 1) / kBlock;
+  const int64_t b0 = static_cast<int64_t>(threadIdx.x) * chunk;
+  int64_t b1 = b0 + chunk;
+  if (b1 > nb) b1 = nb;
+  S acc = Op::identity();
+  for (int64_t i = b0; i < b1; ++i) acc = Op::combine(acc, agg[i]);
+  S total;
+  S run = BlockExclusive<S, Op>(acc, lds, &total);
+  for (int64_t i = b0; i < b1; ++i) {
+    const S v = agg[i];
+    agg[i] = run;
+    run = Op::combine(run, v);
   }
 }
 
@@ -258,7 +264,8 @@ __global__ __launch_bounds__(kBlock) void TvInitKernel(TvState<T> st) {
 template <class T>
 __global__ __launch_bounds__(kBlock) void TvSplitKernel(TvState<T> st, uint8_t* head,
                                                         uint8_t* end, int8_t* cl2, int8_t* cr2,
-                                                        uint16_t* split, uint16_t level) {
+                                                        uint16_t* split, uint16_t level,
+                                                        unsigned long long* cuts) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
   if (i >= st.n) return;
   if (st.done[i]) {
@@ -276,28 +283,23 @@ __global__ __launch_bounds__(kBlock) void TvSplitKernel(TvState<T> st, uint8_t* 
   // across a cut the u = 1 side lies strictly above the u = 0 side
   cl2[i] = old_head ? st.cl[i] : (cut_left ? (ui ? int8_t(1) : int8_t(-1)) : int8_t(0));
   cr2[i] = old_end ? st.cr[i] : (cut_right ? (ui ? int8_t(1) : int8_t(-1)) : int8_t(0));
-  if (cut_right) split[l] = level;
+  if (cut_right) {
+    split[l] = level;
+    atomicAdd(cuts, 1ull);  // few: one per cut point of this level
+  }
 }
 
 // Regions that did not split are constant: write x = tau and retire them.
 template <class T>
 __global__ __launch_bounds__(kBlock) void TvFinishKernel(TvState<T> st, T* x,
-                                                         const uint16_t* split, uint16_t level,
-                                                         unsigned long long* remaining) {
+                                                         const uint16_t* split, uint16_t level) {
   const int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
-  unsigned active = 0;
-  if (i < st.n && !st.done[i]) {
-    const int32_t l = st.L[i], r = st.R[i];
-    if (split[l] != level) {
-      x[i] = static_cast<T>(st.Tau(l, r));
-      st.done[i] = 1;
-    } else {
-      active = 1;
-    }
+  if (i >= st.n || st.done[i]) return;
+  const int32_t l = st.L[i], r = st.R[i];
+  if (split[l] != level) {
+    x[i] = static_cast<T>(st.Tau(l, r));
+    st.done[i] = 1;
   }
-  // one atomic per wave
-  const unsigned long long ballot = __ballot(active);
-  if ((threadIdx.x & 63) == 0 && ballot) atomicAdd(remaining, static_cast<unsigned long long>(__popcll(ballot)));
 }
 
 template <class T> int Tv1dLevelSets(const DVec& xv, const DVec& yv, double lam) {
@@ -347,11 +349,11 @@ template <class T> int Tv1dLevelSets(const DVec& xv, const DVec& yv, double lam)
     RunScan<ClipScanOp<T>, false>(cop, n);
     DecodeScanOp<T> dop{st};
     RunScan<DecodeScanOp<T>, true>(dop, n);
-    hipLaunchKernelGGL(TvSplitKernel<T>, dim3(grid), dim3(kBlock), 0, s, st, head, end, cl2, cr2,
-                       split, static_cast<uint16_t>(level));
     EPS_HIP(hipMemsetAsync(remaining, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(TvSplitKernel<T>, dim3(grid), dim3(kBlock), 0, s, st, head, end, cl2, cr2,
+                       split, static_cast<uint16_t>(level), remaining);
     hipLaunchKernelGGL(TvFinishKernel<T>, dim3(grid), dim3(kBlock), 0, s, st, xv.as<T>(), split,
-                       static_cast<uint16_t>(level), remaining);
+                       static_cast<uint16_t>(level));
     unsigned long long h = 0;
     EPS_HIP(hipMemcpyAsync(&h, remaining, sizeof(h), hipMemcpyDeviceToHost, s));
     EPS_HIP(hipStreamSynchronize(s));
@@ -366,7 +368,11 @@ template <class T> int Tv1dLevelSets(const DVec& xv, const DVec& yv, double lam)
   return level;
 }
 
+int g_last_levels = 0;
+
 }  // namespace
+
+int Tv1dLastLevels() { return g_last_levels; }
 
 void Tv1d(const DVec& x, const DVec& v, double lam) {
   EPS_CHECK(x.n == v.n && x.dt == v.dt);
@@ -377,8 +383,8 @@ void Tv1d(const DVec& x, const DVec& v, double lam) {
     Copy(x, v);
     return;
   }
-  if (x.dt == F32) Tv1dLevelSets<float>(x, v, lam);
-  else Tv1dLevelSets<double>(x, v, lam);
+  if (x.dt == F32) g_last_levels = Tv1dLevelSets<float>(x, v, lam);
+  else g_last_levels = Tv1dLevelSets<double>(x, v, lam);
 }
 
 }  // namespace k

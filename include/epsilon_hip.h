@@ -174,6 +174,11 @@ int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg);
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
 int eps_tv1d(const double* v, size_t n, double lam, double* x);
 
+/* The same on device-resident data: v, x are device pointers to n elements of `kind`
+ * (EPS_BLOB_DEVICE_F32 / EPS_BLOB_DEVICE_F64); *levels (may be NULL) receives the depth of the
+ * level-set recursion.  Synchronises before returning. */
+int eps_tv1d_device(const void* v_dev, void* x_dev, size_t n, int kind, double lam, int* levels);
+
 #ifdef __cplusplus
 }
 #endif
