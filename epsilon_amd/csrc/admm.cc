@@ -142,6 +142,8 @@ class ProxADMMSolver final : public Solver {
   void Init() override {  // :110-129
     SetCurrentDType(data_->dtype());
     const double t0 = Now();
+    if (op_cache_.size() > 64) op_cache_.Clear();
+    OpCacheScope cache_scope(&op_cache_);
     InitConstraints();
     InitProxOperators();
     if (!params_.warm_start || !vars_initialized_) {
@@ -457,6 +459,8 @@ class ProxADMMTwoBlockSolver final : public Solver {
   void Init() override {  // :21-94
     SetCurrentDType(data_->dtype());
     const double t0 = Now();
+    if (op_cache_.size() > 64) op_cache_.Clear();
+    OpCacheScope cache_scope(&op_cache_);
     const double sqrt_rho = std::sqrt(params_.rho);
     const DType dt = data_->dtype();
     AffineOperator H, A;

@@ -60,6 +60,8 @@ class Solver {
   bool finished_ = false;
   double init_seconds_ = 0, loop_seconds_ = 0;
   std::function<void(const std::string&)> log_;
+  // Gram products / inverses of previous Inits of this solver, by content id (warm start).
+  OpCache op_cache_;
 };
 
 std::unique_ptr<Solver> CreateSolver(pb::Problem problem, std::shared_ptr<DataMap> data,

@@ -19,6 +19,32 @@ const char* ImplTypeName(ImplType t) {
   }
 }
 
+// ---- content ids / OpCache ---------------------------------------------------------------------------
+
+uint64_t HashCombine(uint64_t h, uint64_t v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  return h;
+}
+
+uint64_t HashBytes(const void* p, size_t n, uint64_t seed) {
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  uint64_t h = 1469598103934665603ull ^ seed;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= b[i];
+    h *= 1099511628211ull;
+  }
+  return h ? h : 1;
+}
+
+namespace {
+thread_local OpCache* g_op_cache = nullptr;
+}
+OpCache* CurrentOpCache() { return g_op_cache; }
+OpCacheScope::OpCacheScope(OpCache* c) : saved(g_op_cache) { g_op_cache = c; }
+OpCacheScope::~OpCacheScope() { g_op_cache = saved; }
+
 // ---- DataMap --------------------------------------------------------------------------------------
 
 const Blob& DataMap::Get(const std::string& key) const {
@@ -69,6 +95,17 @@ DVec DataMap::DenseDevice(const pb::Constant& c_in) {
   return v;
 }
 
+uint64_t DataMap::DenseId(const pb::Constant& c_in) const {
+  const pb::Constant& c = Resolve(c_in);
+  if (c.data_location.empty()) return 0;
+  const Blob& b = Get(c.data_location);
+  uint64_t h = HashBytes(c.data_location.data(), c.data_location.size(), 0x5eed);
+  h = HashCombine(h, reinterpret_cast<uintptr_t>(b.ptr));
+  h = HashCombine(h, b.len);
+  h = HashCombine(h, static_cast<uint64_t>(c.m) << 32 | static_cast<uint32_t>(c.n));
+  return h ? h : 1;
+}
+
 std::vector<double> DataMap::DenseHost(const pb::Constant& c_in) {
   const pb::Constant& c = Resolve(c_in);
   EPS_CHECK_MSG(c.constant_type == pb::Constant::DENSE_MATRIX, "constant is not a dense matrix");
@@ -103,9 +140,9 @@ LinearMap LinearMap::Scalar(double alpha, int64_t n) {
 LinearMap LinearMap::Diagonal(std::vector<double> d, DType dt) {
   return LinearMap(std::make_shared<DiagonalMatrixImpl>(std::move(d), dt));
 }
-LinearMap LinearMap::Dense(DVec data, int64_t rows, int64_t cols) {
+LinearMap LinearMap::Dense(DVec data, int64_t rows, int64_t cols, uint64_t id) {
   EPS_CHECK(data.n == rows * cols);
-  return LinearMap(std::make_shared<DenseMatrixImpl>(std::move(data), rows, cols, false, 1.0));
+  return LinearMap(std::make_shared<DenseMatrixImpl>(std::move(data), rows, cols, false, 1.0, id));
 }
 LinearMap LinearMap::Kronecker(LinearMap A, LinearMap B) {
   return LinearMap(std::make_shared<KroneckerProductImpl>(std::move(A), std::move(B)));
@@ -198,7 +235,7 @@ std::string DenseMatrixImpl::DebugString() const {
   return os.str();
 }
 std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Transpose() const {
-  return std::make_shared<DenseMatrixImpl>(data_, rows_, cols_, !trans_, scale_);
+  return std::make_shared<DenseMatrixImpl>(data_, rows_, cols_, !trans_, scale_, id_);
 }
 DVec DenseMatrixImpl::Materialize(bool force_copy) const {
   if (!trans_ && scale_ == 1.0 && !force_copy) return data_;
@@ -220,10 +257,19 @@ std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Inverse() const {
     d0 = h[0] * scale_;
   }
   const double sign = d0 < 0 ? -1.0 : 1.0;
+  uint64_t key = 0;
+  OpCache* cache = CurrentOpCache();
+  if (cache && id_) {
+    key = HashDouble(HashCombine(HashCombine(id_, 0x1171), trans_ ? 2 : 1), scale_);
+    if (auto hit = cache->Find(key))
+      return std::make_shared<DenseMatrixImpl>(hit->data(), nn, nn, false, sign, key);
+  }
   DVec W = DVec::Empty(nn * nn, data_.dt);
   k::MatCopy(trans_, nn, nn, sign * scale_, data_, rows_, W);
   k::SpdInverseInPlace(W, nn);
-  return std::make_shared<DenseMatrixImpl>(W, nn, nn, false, sign);
+  auto result = std::make_shared<DenseMatrixImpl>(W, nn, nn, false, sign, key);
+  if (cache && key) cache->Put(key, result);
+  return result;
 }
 bool DenseMatrixImpl::Equals(const LinearMapImpl& o) const {
   if (o.type() != DENSE_MATRIX || o.m() != m() || o.n() != n()) return false;
@@ -372,14 +418,27 @@ DType PairDType(const LinearMapImpl& a, const LinearMapImpl& b) {
 ImplPtr MultiplyDenseDense(const DenseMatrixImpl& A, const DenseMatrixImpl& B) {
   // reference :14-37 dgemm_ with the operands' trans flags
   const int64_t M = A.m(), K = A.n(), N = B.n();
+  // The product of the raw buffers is memoised by content id; the operands' lazy scalar
+  // factors ride on the result as its lazy factor.
+  const double scale = A.scale() * B.scale();
+  uint64_t key = 0;
+  OpCache* cache = CurrentOpCache();
+  if (cache && A.id() && B.id()) {
+    key = HashCombine(HashCombine(HashCombine(A.id(), 0x6d756c), B.id()),
+                      (A.trans() ? 2 : 0) + (B.trans() ? 1 : 0));
+    if (auto hit = cache->Find(key))
+      return std::make_shared<DenseMatrixImpl>(hit->data(), M, N, false, scale, key);
+  }
   DVec C = DVec::Empty(M * N, A.dtype());
   // A * A^T (or A^T * A) of one shared buffer: compute the lower triangle only and mirror
   const bool syrk = A.data().data() == B.data().data() && A.rows() == B.rows() &&
                     A.cols() == B.cols() && A.trans() != B.trans() && M == N;
-  k::Gemm(A.trans(), B.trans(), M, N, K, A.scale() * B.scale(), A.data(), A.rows(), B.data(),
-          B.rows(), 0.0, C, M, syrk);
+  k::Gemm(A.trans(), B.trans(), M, N, K, 1.0, A.data(), A.rows(), B.data(), B.rows(), 0.0, C, M,
+          syrk);
   if (syrk) k::SymmetrizeFromLower(C, M, M);
-  return std::make_shared<DenseMatrixImpl>(C, M, N, false, 1.0);
+  auto unit = std::make_shared<DenseMatrixImpl>(C, M, N, false, 1.0, key);
+  if (cache && key) cache->Put(key, unit);
+  return std::make_shared<DenseMatrixImpl>(C, M, N, false, scale, key);
 }
 
 ImplPtr MultiplyViaDense(const LinearMapImpl& L, const LinearMapImpl& R) {
@@ -416,7 +475,7 @@ ImplPtr Multiply(const LinearMapImpl& L, const LinearMapImpl& R) {
       case DENSE_MATRIX: {
         const auto& D = static_cast<const DenseMatrixImpl&>(R);
         return std::make_shared<DenseMatrixImpl>(D.data(), D.rows(), D.cols(), D.trans(),
-                                                 S.alpha() * D.scale());
+                                                 S.alpha() * D.scale(), D.id());
       }
       case KRONECKER_PRODUCT:
         return MultiplyScalarKron(S, static_cast<const KroneckerProductImpl&>(R));
@@ -435,7 +494,7 @@ ImplPtr Multiply(const LinearMapImpl& L, const LinearMapImpl& R) {
       case DENSE_MATRIX: {
         const auto& D = static_cast<const DenseMatrixImpl&>(L);
         return std::make_shared<DenseMatrixImpl>(D.data(), D.rows(), D.cols(), D.trans(),
-                                                 D.scale() * S.alpha());
+                                                 D.scale() * S.alpha(), D.id());
       }
       case KRONECKER_PRODUCT:  // reference :223-227 delegates with swapped arguments
         return MultiplyScalarKron(S, static_cast<const KroneckerProductImpl&>(L));
@@ -530,9 +589,19 @@ ImplPtr Add(const LinearMapImpl& L, const LinearMapImpl& R) {
       return std::make_shared<DenseMatrixImpl>(C, L.m(), L.n(), false, 1.0);
     }
     if (O.type() == SCALAR_MATRIX) {
+      const double a = static_cast<const ScalarMatrixImpl&>(O).alpha();
+      uint64_t key = 0;
+      OpCache* cache = CurrentOpCache();
+      if (cache && D.id()) {
+        key = HashDouble(HashDouble(HashCombine(HashCombine(D.id(), 0xadd5), D.trans() ? 2 : 1),
+                                    D.scale()), a);
+        if (auto hit = cache->Find(key)) return hit;
+      }
       DVec C = D.Materialize(true);
-      k::AddDiag(C, D.m(), D.m(), static_cast<const ScalarMatrixImpl&>(O).alpha(), nullptr);
-      return std::make_shared<DenseMatrixImpl>(C, D.m(), D.n(), false, 1.0);
+      k::AddDiag(C, D.m(), D.m(), a, nullptr);
+      auto result = std::make_shared<DenseMatrixImpl>(C, D.m(), D.n(), false, 1.0, key);
+      if (cache && key) cache->Put(key, result);
+      return result;
     }
     if (O.type() == DIAGONAL_MATRIX) {
       DVec C = D.Materialize(true);
@@ -571,7 +640,7 @@ LinearMap BuildLinearMap(const pb::LinearMap& p, DataMap* data) {
   switch (p.linear_map_type) {
     case pb::LinearMap::DENSE_MATRIX: {
       const pb::Constant& c = data->Resolve(p.constant);
-      return LinearMap::Dense(data->DenseDevice(c), c.m, c.n);
+      return LinearMap::Dense(data->DenseDevice(c), c.m, c.n, data->DenseId(c));
     }
     case pb::LinearMap::DIAGONAL_MATRIX:
       return LinearMap::Diagonal(data->DenseHost(p.constant), data->dtype());

@@ -73,6 +73,8 @@ class DataMap {
   const Blob& Get(const std::string& key) const;
   // Dense constant as a device vector of m*n entries (column-major), compute dtype.
   DVec DenseDevice(const pb::Constant& c);
+  // Content id of a dense constant (location + blob identity), for the OpCache.
+  uint64_t DenseId(const pb::Constant& c) const;
   // Dense constant as host doubles (diagonals, small vectors).
   std::vector<double> DenseHost(const pb::Constant& c);
   // Values bound to CVXPY Parameters for this call (reference solver.cc:109-116).
@@ -101,7 +103,7 @@ class LinearMap {  // reference linear/linear_map.h:61-92
   static LinearMap Scalar(double alpha, int64_t n);
   static LinearMap Diagonal(std::vector<double> d, DType dt);
   // Takes ownership of a column-major device buffer (rows x cols).
-  static LinearMap Dense(DVec data, int64_t rows, int64_t cols);
+  static LinearMap Dense(DVec data, int64_t rows, int64_t cols, uint64_t id = 0);
   static LinearMap Kronecker(LinearMap A, LinearMap B);
 
  private:
@@ -166,9 +168,13 @@ class DiagonalMatrixImpl final : public LinearMapImpl {  // linear/diagonal_matr
 class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_impl.h:13-60
  public:
   // op(data) * scale, data is rows x cols column-major (ld = rows)
-  DenseMatrixImpl(DVec data, int64_t rows, int64_t cols, bool trans, double scale)
+  // `id` names the CONTENT of the buffer (0 = anonymous).  Results of the setup algebra get ids
+  // derived from their operands' ids, so a later Init with the same matrices (warm start,
+  // re-bound vector parameters) finds them in the OpCache instead of redoing GEMM / inverse.
+  DenseMatrixImpl(DVec data, int64_t rows, int64_t cols, bool trans, double scale,
+                  uint64_t id = 0)
       : LinearMapImpl(DENSE_MATRIX), data_(std::move(data)), rows_(rows), cols_(cols),
-        trans_(trans), scale_(scale) {}
+        trans_(trans), scale_(scale), id_(id) {}
   int64_t m() const override { return trans_ ? cols_ : rows_; }
   int64_t n() const override { return trans_ ? rows_ : cols_; }
   std::string DebugString() const override;
@@ -183,6 +189,7 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   int64_t cols() const { return cols_; }
   bool trans() const { return trans_; }
   double scale() const { return scale_; }
+  uint64_t id() const { return id_; }
   DType dtype() const { return data_.dt; }
   // Contiguous m() x n() buffer holding scale*op(data) (a fresh copy unless already plain).
   DVec Materialize(bool force_copy) const;
@@ -192,7 +199,38 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   int64_t rows_, cols_;
   bool trans_;
   double scale_;
+  uint64_t id_;
 };
+
+// Memo of dense setup results (Gram products, sums, explicit inverses) keyed by content id.
+// One per solver handle; installed for the duration of Solver::Init by OpCacheScope.
+class OpCache {
+ public:
+  std::shared_ptr<const DenseMatrixImpl> Find(uint64_t key) const {
+    auto it = map_.find(key);
+    return it == map_.end() ? nullptr : it->second;
+  }
+  void Put(uint64_t key, std::shared_ptr<const DenseMatrixImpl> v) { map_[key] = std::move(v); }
+  size_t size() const { return map_.size(); }
+  void Clear() { map_.clear(); }
+
+ private:
+  std::map<uint64_t, std::shared_ptr<const DenseMatrixImpl>> map_;
+};
+OpCache* CurrentOpCache();
+struct OpCacheScope {
+  OpCache* saved;
+  explicit OpCacheScope(OpCache* c);
+  ~OpCacheScope();
+};
+uint64_t HashCombine(uint64_t h, uint64_t v);
+uint64_t HashBytes(const void* p, size_t n, uint64_t seed);
+inline uint64_t HashDouble(uint64_t h, double d) {
+  uint64_t b;
+  static_assert(sizeof(b) == sizeof(d), "");
+  __builtin_memcpy(&b, &d, 8);
+  return HashCombine(h, b);
+}
 
 class KroneckerProductImpl final : public LinearMapImpl {  // linear/kronecker_product_impl.h
  public:

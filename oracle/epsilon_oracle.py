@@ -303,7 +303,21 @@ def get_diagonal(A):  # linear/linear_map.cc:118-129
 # ---- proto -> linear map (linear/linear_map.cc:39-104), data decoders (vector/vector_util.cc) ---
 
 
+PARAMS_KEY = "\0parameters"  # {parameter_id: Constant} bound for this call (solver.cc:109-116)
+
+
+def resolve_constant(c, data):
+    """A Constant carrying a parameter_id stands for the value bound to that CVXPY Parameter
+    (reference algorithms/solver.cc:30-61,109-116 overwrites the proto in place)."""
+    if c.parameter_id:
+        bound = data.get(PARAMS_KEY, {})
+        check(c.parameter_id in bound, "parameter %s has no value" % c.parameter_id)
+        return bound[c.parameter_id]
+    return c
+
+
 def build_matrix(c, data):  # vector/vector_util.cc:247-259
+    c = resolve_constant(c, data)
     check(c.constant_type == wire.Constant.DENSE_MATRIX)
     check(c.data_location in data, "missing data " + c.data_location)
     buf = data[c.data_location]
@@ -700,7 +714,7 @@ def build_affine_operator(e, data, row_key, A, b, L=None):  # affine.cc:22-129
     elif t == Expression.VARIABLE:  # :41-49
         A.insert_or_add(row_key, e.variable.variable_id, L)
     elif t == Expression.CONSTANT:  # :51-69
-        c = e.constant
+        c = resolve_constant(e.constant, data)
         if c.data_location == "":
             b_dense = np.full(L.n, c.scalar)
         else:
@@ -1361,6 +1375,9 @@ def solve(problem_bytes, parameters, params_bytes, data, trace=None):
     """solvemodule.cc:110-187 -> (SolverStatus bytes, {var_id: float64 bytes})."""
     problem = wire.Problem.FromString(problem_bytes)
     params = wire.SolverParams.FromString(params_bytes)
+    if parameters:
+        data = dict(data)
+        data[PARAMS_KEY] = {pid: wire.Constant.FromString(cb) for pid, cb in parameters}
     solver = create_solver(problem, data, params)
     solver.trace = trace
     x = solver.solve()

@@ -477,3 +477,83 @@ def test_tv1d_parallel_kernel(solve_mod, dtype, case):
         assert bound < 1e-7 and jump < 1e-7 and end < 1e-7
     if case == "tiny":
         np.testing.assert_allclose(got, [1.0, 9.0])
+
+
+def lasso_with_parameter(m, n, seed):
+    """Compiled lasso whose right-hand side b is a CVXPY Parameter (a CONSTANT carrying a
+    parameter_id, reference python/epopt/expression.py:227-236)."""
+    A, b = problems.regression_data(m, n, seed=seed)
+    lam = 0.3 * np.abs(A.T.dot(b)).max()
+    prob = problems.lasso_ir(ir.dense_matrix(A), ir.parameter(m, 1, "param:b"), lam, n)
+    return prob, A, b, lam
+
+
+def bind(b):
+    data = {}
+    c = ir.store(np.asarray(b, dtype=np.float64).reshape(-1, 1), data)
+    return ("param:b", c.SerializeToString()), data
+
+
+def test_parameter_binding_one_shot(solve_mod, dtype):
+    """`parameters` argument of _solve.solve (reference solvemodule.cc:89-106)."""
+    prob, A, b, lam = lasso_with_parameter(60, 150, 4)
+    p, pdata = bind(b)
+    data = dict(prob.expression_data())
+    data.update(pdata)
+    sb = wire.SolverParams().SerializeToString()
+    st_g, x_g = solve_mod.solve(prob.SerializeToString(), [p], sb, data)
+    st_o, x_o = orc.solve(prob.SerializeToString(), [p], sb, data)
+    a, o = wire.SolverStatus.FromString(st_g), wire.SolverStatus.FromString(st_o)
+    assert a.state == o.state and a.num_iterations == o.num_iterations
+    tol = dict(rtol=1e-8, atol=1e-10) if dtype == "f64" else dict(rtol=1e-3, atol=1e-4)
+    for k in x_o:
+        np.testing.assert_allclose(np.frombuffer(x_g[k]), np.frombuffer(x_o[k]), **tol)
+
+
+def test_warm_start_reuses_factorisation(solve_mod, dtype):
+    """a live solver handle keeps A and the cached inverse in HBM; re-binding
+    the parameter b and re-running Init() with warm_start redoes no GEMM / inverse and starts
+    from the previous x/y/u (reference solvemodule.cc:142-156, prox_admm.cc:115-120)."""
+    prob, A, b, lam = lasso_with_parameter(96, 240, 5)
+    rng = np.random.RandomState(0)
+    b2 = b + 0.05 * rng.randn(b.size)
+    pb = prob.SerializeToString()
+    sp = wire.SolverParams(warm_start=True)
+    sb = sp.SerializeToString()
+    p1, d1 = bind(b)
+    p2, d2 = bind(b2)
+    data = dict(prob.expression_data())
+    data.update(d1)
+    data.update(d2)
+    s = solve_mod.Solver(pb, sb, data)
+    s.set_parameter(*p1)
+    s.init()
+    s.run(-1)
+    st1, x1 = s.result()
+    solve_mod.profile_reset()
+    solve_mod.profile_enable(True)
+    s.set_parameter(*p2)
+    s.init()
+    tags = solve_mod.profile_dump()
+    solve_mod.profile_enable(False)
+    assert not any(t.startswith(("syrk", "gemm", "spd_inverse")) for t in tags), \
+        "second Init redid dense setup work: %s" % sorted(tags)
+    s.run(-1)
+    st2, x2 = s.result()
+    s.close()
+    # oracle: same two solves on one solver object with warm_start
+    problem = wire.Problem.FromString(pb)
+    odata = dict(data)
+    odata[orc.PARAMS_KEY] = {"param:b": wire.Constant.FromString(p1[1])}
+    osolver = orc.create_solver(problem, odata, sp)
+    osolver.solve()
+    it1 = osolver.status.num_iterations
+    odata[orc.PARAMS_KEY] = {"param:b": wire.Constant.FromString(p2[1])}
+    xo = osolver.solve()
+    it2 = osolver.status.num_iterations
+    a1, a2 = wire.SolverStatus.FromString(st1), wire.SolverStatus.FromString(st2)
+    assert a1.num_iterations == it1 and a2.num_iterations == it2
+    assert it2 <= it1  # the warm start pays off
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
+    for k in x2:
+        np.testing.assert_allclose(np.frombuffer(x2[k]), xo(k), err_msg=k, **tol)
