@@ -95,6 +95,19 @@ void MaxZero(const DVec& x, const DVec& v);
 void Norm2Shrink(const DVec& x, const DVec& v, double lam, const double* normsq);
 // x = soft-threshold of singular values etc. is composed from ScaledZone.
 
+// ---- epigraph projections (reference prox/sum_square.cc:42-57, prox/scaled_zone.cc:152-279) ----
+// SUM_SQUARE epigraph: lam = max(0, largest real root of the cubic of newton.cc:293-323) from
+// ||u||^2 (device slot) and s (1 element); x = u / (1 + 2 lam), t = s + lam.  No host sync.
+void SumSquareEpigraph(const DVec& x, const DVec& t, const DVec& u, const DVec& s,
+                       const double* normsq, double* lam_scratch);
+// Scaled-zone epigraph, pass 1: keys k_i = (|y_i| - M) / w_i and weights w_i^2 for the samples
+// that can move (w = alpha for y > 0, beta for y < 0), zero weight otherwise; *fval += f(y).
+void ZoneEpigraphKeys(const DVec& v, double alpha, double beta, const DVec* alpha_vec,
+                      const DVec* beta_vec, double M, double C, double* key, double* w2,
+                      double* fval);
+// pass 2: sums[0] += sum w2*k, sums[1] += sum w2, sums[2] += count over {k_i > lam, w2_i > 0}
+void ZoneEpigraphSums(int64_t n, const double* key, const double* w2, double lam, double* sums);
+
 // ---- K11: SVD for the orthogonally-invariant proxes (reference prox/ortho_invariant.cc) ------
 // One-sided Jacobi on W (m x n, ld = m): on return W = U*Sigma (orthogonal columns) and the
 // input equals W V^T; V (n x n) is overwritten.  Returns the number of sweeps used.

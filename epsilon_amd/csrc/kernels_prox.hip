@@ -210,5 +210,188 @@ void Tv1dSerial(const DVec& x, const DVec& v, double lam) {
                        x.as<double>(), v.as<double>(), n, lam, static_cast<double*>(ws->p));
 }
 
+// ---- epigraph projections -----------------------------------------------------------------------
+
+namespace {
+
+struct Cplx {
+  double re, im;
+};
+__device__ inline Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ inline Cplx csub(Cplx a, Cplx b) { return {a.re - b.re, a.im - b.im}; }
+__device__ inline Cplx cadd(Cplx a, Cplx b) { return {a.re + b.re, a.im + b.im}; }
+__device__ inline Cplx cdiv(Cplx a, Cplx b) {
+  const double d = b.re * b.re + b.im * b.im;
+  return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+__device__ inline double cabs(Cplx a) { return sqrt(a.re * a.re + a.im * a.im); }
+__device__ inline Cplx cubic(Cplx z, double b, double c, double d) {
+  // z^3 + b z^2 + c z + d
+  Cplx z2 = cmul(z, z), z3 = cmul(z2, z);
+  return {z3.re + b * z2.re + c * z.re + d, z3.im + b * z2.im + c * z.im};
+}
+
+// reference prox/newton.cc:293-323 (Durand-Kerner, same start values and tolerances)
+__device__ double LargestRealCubicRootDev(double b, double c, double d) {
+  const double eps = 1e-12;
+  Cplx p{0.4, 0.9};
+  Cplx q = cmul(p, p), r = cmul(q, p);
+  for (int it = 0; it < 100; ++it) {
+    Cplx fp = cubic(p, b, c, d), fq = cubic(q, b, c, d), fr = cubic(r, b, c, d);
+    if (cabs(fp) < eps && cabs(fq) < eps && cabs(fr) < eps) break;
+    Cplx np = csub(p, cdiv(fp, cmul(csub(p, q), csub(p, r))));
+    Cplx nq = csub(q, cdiv(fq, cmul(csub(q, p), csub(q, r))));
+    Cplx nr = csub(r, cdiv(fr, cmul(csub(r, p), csub(r, q))));
+    p = np;
+    q = nq;
+    r = nr;
+  }
+  double m = -1e41;
+  if (fabs(p.im) < eps && p.re > m) m = p.re;
+  if (fabs(q.im) < eps && q.re > m) m = q.re;
+  if (fabs(r.im) < eps && r.re > m) m = r.re;
+  return m;
+}
+
+template <class T>
+__global__ void SumSquareEpiScalarKernel(const T* s, const double* normsq, double* lam_out, T* t) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double sv = static_cast<double>(*s);
+  double lam = LargestRealCubicRootDev(1 + sv, 0.25 + sv, (sv - *normsq) / 4);
+  if (lam < 0) lam = 0;
+  *lam_out = lam;
+  *t = static_cast<T>(sv + lam);
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void ScaleByLamKernel(T* x, const T* u, int64_t n,
+                                                           const double* lam) {
+  const T f = static_cast<T>(1.0 / (1.0 + 2.0 * *lam));
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  // the reference divides: x = u / (1 + 2 lam)
+  const double denom = 1.0 + 2.0 * *lam;
+  (void)f;
+  for (int64_t i = tid; i < n; i += stride) x[i] = static_cast<T>(static_cast<double>(u[i]) / denom);
+}
+
+__device__ inline double WaveSumP(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void ZoneKeysKernel(const T* v, int64_t n, double alpha_s,
+                                                         double beta_s, const T* alpha_v,
+                                                         const T* beta_v, double M, double C,
+                                                         double* key, double* w2, double* fval) {
+  __shared__ double red[kBlock / 64];
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double f = 0;
+  for (int64_t i = tid; i < n; i += stride) {
+    const double y = static_cast<double>(v[i]) - C;
+    const double a = alpha_v ? static_cast<double>(alpha_v[i]) : alpha_s;
+    const double b = beta_v ? static_cast<double>(beta_v[i]) : beta_s;
+    const double w = y > 0 ? a : b;
+    double kk = 0, ww = 0;
+    if (fabs(y) > M && w != 0) {  // reference filter, scaled_zone.cc:185-188
+      const double ex = fabs(y) - M;
+      f += w * ex;
+      kk = ex / w;
+      ww = w * w;
+    }
+    key[i] = kk;
+    w2[i] = ww;
+  }
+  f = WaveSumP(f);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+    atomicAdd(fval, t);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void ZoneSumsKernel(int64_t n, const double* key,
+                                                         const double* w2, double lam,
+                                                         double* sums) {
+  __shared__ double red[kBlock / 64][3];
+  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  double a = 0, b = 0, c = 0;
+  for (int64_t i = tid; i < n; i += stride) {
+    const double ww = w2[i], kk = key[i];
+    if (ww > 0 && kk > lam) {
+      a += ww * kk;
+      b += ww;
+      c += 1;
+    }
+  }
+  a = WaveSumP(a);
+  b = WaveSumP(b);
+  c = WaveSumP(c);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6][0] = a;
+    red[threadIdx.x >> 6][1] = b;
+    red[threadIdx.x >> 6][2] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0, tb = 0, tc = 0;
+    for (int w = 0; w < kBlock / 64; ++w) {
+      ta += red[w][0];
+      tb += red[w][1];
+      tc += red[w][2];
+    }
+    atomicAdd(&sums[0], ta);
+    atomicAdd(&sums[1], tb);
+    atomicAdd(&sums[2], tc);
+  }
+}
+
+}  // namespace
+
+void SumSquareEpigraph(const DVec& x, const DVec& t, const DVec& u, const DVec& s,
+                       const double* normsq, double* lam_scratch) {
+  EPS_CHECK(x.n == u.n && x.dt == u.dt && t.n == 1 && s.n == 1 && t.dt == x.dt && s.dt == x.dt);
+  hipStream_t st = Runtime::Get().stream();
+  if (x.dt == F32) {
+    hipLaunchKernelGGL(SumSquareEpiScalarKernel<float>, dim3(1), dim3(64), 0, st, s.as<float>(),
+                       normsq, lam_scratch, t.as<float>());
+    if (x.n) hipLaunchKernelGGL(ScaleByLamKernel<float>, dim3(GridFor(x.n)), dim3(kBlock), 0, st,
+                                x.as<float>(), u.as<float>(), x.n, lam_scratch);
+  } else {
+    hipLaunchKernelGGL(SumSquareEpiScalarKernel<double>, dim3(1), dim3(64), 0, st, s.as<double>(),
+                       normsq, lam_scratch, t.as<double>());
+    if (x.n) hipLaunchKernelGGL(ScaleByLamKernel<double>, dim3(GridFor(x.n)), dim3(kBlock), 0, st,
+                                x.as<double>(), u.as<double>(), x.n, lam_scratch);
+  }
+}
+
+void ZoneEpigraphKeys(const DVec& v, double alpha, double beta, const DVec* alpha_vec,
+                      const DVec* beta_vec, double M, double C, double* key, double* w2,
+                      double* fval) {
+  if (v.n == 0) return;
+  hipStream_t st = Runtime::Get().stream();
+  if (v.dt == F32)
+    hipLaunchKernelGGL(ZoneKeysKernel<float>, dim3(GridFor(v.n)), dim3(kBlock), 0, st, v.as<float>(),
+                       v.n, alpha, beta, alpha_vec ? alpha_vec->as<float>() : nullptr,
+                       beta_vec ? beta_vec->as<float>() : nullptr, M, C, key, w2, fval);
+  else
+    hipLaunchKernelGGL(ZoneKeysKernel<double>, dim3(GridFor(v.n)), dim3(kBlock), 0, st,
+                       v.as<double>(), v.n, alpha, beta,
+                       alpha_vec ? alpha_vec->as<double>() : nullptr,
+                       beta_vec ? beta_vec->as<double>() : nullptr, M, C, key, w2, fval);
+}
+
+void ZoneEpigraphSums(int64_t n, const double* key, const double* w2, double lam, double* sums) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(ZoneSumsKernel, dim3(GridFor(n)), dim3(kBlock), 0, Runtime::Get().stream(), n,
+                     key, w2, lam, sums);
+}
+
 }  // namespace k
 }  // namespace eps

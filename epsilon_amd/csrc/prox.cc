@@ -198,35 +198,45 @@ ZoneParam PromoteParam(const DVec& x, int64_t n) {  // scaled_zone.cc:26-32
   return p;
 }
 
+// GetParams, reference prox/scaled_zone.cc:34-76
+void InitZoneParams(const ProxOperatorArg& arg, ZoneParam* alpha, ZoneParam* beta, double* M,
+                    int64_t* n) {
+  const pb::ProxFunction& f = arg.prox_function();
+  EPS_CHECK_MSG(!f.arg_size.empty() && f.arg_size[0].dim.size() == 2,
+                "scaled zone prox needs arg_size");
+  if (f.has_axis) *n = f.arg_size[0].dim[f.axis];
+  else *n = static_cast<int64_t>(f.arg_size[0].dim[0]) * f.arg_size[0].dim[1];
+  *alpha = ZoneParam();
+  *beta = ZoneParam();
+  alpha->value = 1;
+  beta->value = 1;
+  *M = 0;
+  switch (f.prox_function_type) {  // scaled_zone.cc:46-72
+    case pb::ProxFunction::NORM_1: break;
+    case pb::ProxFunction::SUM_DEADZONE: *M = f.sz_m; break;
+    case pb::ProxFunction::SUM_HINGE: beta->value = 0; break;
+    case pb::ProxFunction::SUM_QUANTILE: {
+      EPS_CHECK_MSG(f.sz_alpha_expr && f.sz_beta_expr, "SUM_QUANTILE needs alpha/beta exprs");
+      BlockVector tmp;
+      affine::BuildAffineOperator(*f.sz_alpha_expr, arg.data_map(), "alpha", nullptr, &tmp);
+      affine::BuildAffineOperator(*f.sz_beta_expr, arg.data_map(), "beta", nullptr, &tmp);
+      *alpha = PromoteParam(tmp("alpha"), *n);
+      *beta = PromoteParam(tmp("beta"), *n);
+      break;
+    }
+    default: EPS_FATAL("Unknown prox type: " << f.prox_function_type);
+  }
+}
+
 class ScaledZoneProx final : public VectorProx {
  public:
   void Init(const ProxOperatorArg& arg) override {
     VectorProx::Init(arg);
     const pb::ProxFunction& f = arg.prox_function();
-    EPS_CHECK_MSG(!f.arg_size.empty() && f.arg_size[0].dim.size() == 2,
-                  "scaled zone prox needs arg_size");
-    if (f.has_axis) n_ = f.arg_size[0].dim[f.axis];
-    else n_ = static_cast<int64_t>(f.arg_size[0].dim[0]) * f.arg_size[0].dim[1];
+    InitZoneParams(arg, &alpha_, &beta_, &M_, &n_);
     rows_ = f.arg_size[0].dim[0];
     has_axis_ = f.has_axis;
     axis_ = f.axis;
-    alpha_.value = 1;
-    beta_.value = 1;
-    switch (f.prox_function_type) {  // scaled_zone.cc:46-72
-      case pb::ProxFunction::NORM_1: break;
-      case pb::ProxFunction::SUM_DEADZONE: M_ = f.sz_m; break;
-      case pb::ProxFunction::SUM_HINGE: beta_.value = 0; break;
-      case pb::ProxFunction::SUM_QUANTILE: {
-        EPS_CHECK_MSG(f.sz_alpha_expr && f.sz_beta_expr, "SUM_QUANTILE needs alpha/beta exprs");
-        BlockVector tmp;
-        affine::BuildAffineOperator(*f.sz_alpha_expr, arg.data_map(), "alpha", nullptr, &tmp);
-        affine::BuildAffineOperator(*f.sz_beta_expr, arg.data_map(), "beta", nullptr, &tmp);
-        alpha_ = PromoteParam(tmp("alpha"), n_);
-        beta_ = PromoteParam(tmp("beta"), n_);
-        break;
-      }
-      default: EPS_FATAL("Unknown prox type: " << f.prox_function_type);
-    }
   }
 
  protected:
@@ -273,6 +283,80 @@ REGISTER_PROX_OPERATOR(NORM_1, ScaledZoneProx);
 REGISTER_PROX_OPERATOR(SUM_DEADZONE, ScaledZoneProx);
 REGISTER_PROX_OPERATOR(SUM_HINGE, ScaledZoneProx);
 REGISTER_PROX_OPERATOR(SUM_QUANTILE, ScaledZoneProx);
+
+// ---- ScaledZoneEpigraph: projection onto {(x, t): f(x) <= t} (reference scaled_zone.cc:123-284) --
+// The multiplier lam >= 0 is the root of  sum_i w_i^2 max(k_i - lam, 0) = s + lam  (keys k_i,
+// weights w_i as in ZoneEpigraphKeys).  The reference finds it with a randomised 3-way-partition
+// selection on the host (`random()`, :198); here the active set {k_i > lam} is shrunk by
+// Michelot's fixed-point iteration - a masked device reduction per step, finite and exact -
+// which lands on the same lam = acc / (div + 1) (:276).
+
+class ScaledZoneEpigraph final : public VectorProx {
+ public:
+  void Init(const ProxOperatorArg& arg) override {
+    VectorProx::Init(arg);
+    EPS_CHECK_MSG(!arg.prox_function().has_axis, "epigraph with an axis is not supported yet");
+    InitZoneParams(arg, &alpha_, &beta_, &M_, &n_);
+  }
+
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    const DVec& sv = input.value_vec(1);
+    EPS_CHECK(sv.n == 1);
+    Runtime& rt = Runtime::Get();
+    const double s = sv.ToHost()[0];
+    auto keys = rt.Alloc(v.n * sizeof(double)), w2 = rt.Alloc(v.n * sizeof(double));
+    auto sums = rt.Alloc(4 * sizeof(double));
+    double* dk = static_cast<double*>(keys->p);
+    double* dw = static_cast<double*>(w2->p);
+    double* ds = static_cast<double*>(sums->p);
+    EPS_HIP(hipMemsetAsync(ds, 0, 4 * sizeof(double), rt.stream()));
+    k::ZoneEpigraphKeys(v, alpha_.value, beta_.value, alpha_.is_vec ? &alpha_.vec : nullptr,
+                        beta_.is_vec ? &beta_.vec : nullptr, M_, 0.0, dk, dw, ds + 3);
+    double h[4];
+    EPS_HIP(hipMemcpyAsync(h, ds, sizeof(h), hipMemcpyDeviceToHost, rt.stream()));
+    rt.Sync();
+    if (h[3] <= s) {  // already inside the epigraph (:191-195)
+      output->set_value(0, v);
+      output->set_value(1, sv);
+      return;
+    }
+    double lam = 0, count = -1;
+    for (int it = 0; it < 200; ++it) {
+      EPS_HIP(hipMemsetAsync(ds, 0, 3 * sizeof(double), rt.stream()));
+      k::ZoneEpigraphSums(v.n, dk, dw, lam, ds);
+      EPS_HIP(hipMemcpyAsync(h, ds, 3 * sizeof(double), hipMemcpyDeviceToHost, rt.stream()));
+      rt.Sync();
+      // Newton step of the convex piecewise-linear phi(lam) = sum w^2 max(k - lam, 0) - s - lam
+      // from the left: the iterates increase, the active sets are nested, and when the set
+      // that produced lam is still the active set at lam, lam is the exact root.
+      if (h[2] == count) break;
+      count = h[2];
+      lam = (h[0] - s) / (h[1] + 1.0);
+    }
+    DVec x = DVec::Empty(v.n, v.dt);
+    k::ScaledZoneArgs a;
+    a.M = M_;
+    a.alpha = alpha_.value;
+    a.beta = beta_.value;
+    if (alpha_.is_vec) a.alpha_vec = &alpha_.vec;
+    if (beta_.is_vec) a.beta_vec = &beta_.vec;
+    a.lam = lam;
+    k::ScaledZone(x, v, a);
+    output->set_value(0, x);
+    output->set_value(1, DVec::Full(1, s + lam, v.dt));
+  }
+
+ private:
+  ZoneParam alpha_, beta_;
+  double M_ = 0;
+  int64_t n_ = 0;
+};
+REGISTER_EPIGRAPH_OPERATOR(NORM_1, ScaledZoneEpigraph);
+REGISTER_EPIGRAPH_OPERATOR(SUM_DEADZONE, ScaledZoneEpigraph);
+REGISTER_EPIGRAPH_OPERATOR(SUM_HINGE, ScaledZoneEpigraph);
+REGISTER_EPIGRAPH_OPERATOR(SUM_QUANTILE, ScaledZoneEpigraph);
 
 // ---- Norm2Prox (reference prox/norm_2.cc:4-19) ---------------------------------------------------------
 
@@ -378,6 +462,27 @@ class SumSquareProx final : public ProxOperator {
   std::set<std::string> var_keys_;
 };
 REGISTER_PROX_OPERATOR(SUM_SQUARE, SumSquareProx);
+
+// ---- SumSquareEpigraph: ||x||^2 <= t (reference prox/sum_square.cc:42-57) ------------------------------
+
+class SumSquareEpigraph final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& u = input.value_vec(0);
+    const DVec& s = input.value_vec(1);
+    if (!scratch_) scratch_ = Runtime::Get().Alloc(2 * sizeof(double));
+    double* normsq = static_cast<double*>(scratch_->p);
+    k::SumSq(u, normsq, false);
+    DVec x = DVec::Empty(u.n, u.dt), t = DVec::Empty(1, u.dt);
+    k::SumSquareEpigraph(x, t, u, s, normsq, normsq + 1);
+    output->set_value(0, x);
+    output->set_value(1, t);
+  }
+
+ private:
+  std::shared_ptr<Buffer> scratch_;
+};
+REGISTER_EPIGRAPH_OPERATOR(SUM_SQUARE, SumSquareEpigraph);
 
 // ---- ZeroProx: I(H(x) = 0) (reference prox/zero.cc:10-36) ---------------------------------------------
 

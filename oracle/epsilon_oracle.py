@@ -922,6 +922,70 @@ class ScaledZoneProx(VectorProx):  # prox/scaled_zone.cc:106-121
         return [apply_scaled_zone(self.alpha, self.beta, self.M, self.Cc, self.lam_vec, ins[0])]
 
 
+def largest_real_cubic_root(b, c, d):
+    """prox/newton.cc:293-323: Durand-Kerner on x^3 + b x^2 + c x + d, largest real root."""
+    eps = 1e-12
+    p = complex(0.4, 0.9)
+    q, r = p * p, p * p * p
+    for _ in range(100):
+        fp = p * p * p + b * p * p + c * p + d
+        fq = q * q * q + b * q * q + c * q + d
+        fr = r * r * r + b * r * r + c * r + d
+        if abs(fp) < eps and abs(fq) < eps and abs(fr) < eps:
+            break
+        p, q, r = (p - fp / ((p - q) * (p - r)), q - fq / ((q - p) * (q - r)),
+                   r - fr / ((r - p) * (r - q)))
+    m = -1e41
+    for z in (p, q, r):
+        if abs(z.imag) < eps and z.real > m:
+            m = z.real
+    return m
+
+
+class SumSquareEpigraph(VectorProx):  # prox/sum_square.cc:42-57
+    def apply_vector(self, ins):
+        u, s = ins[0], float(ins[1][0])
+        lam = largest_real_cubic_root(1 + s, 0.25 + s, (s - float(u @ u)) / 4)
+        if lam < 0:
+            lam = 0.0
+        return [u / (1 + 2 * lam), np.array([s + lam])]
+
+
+class ScaledZoneEpigraph(VectorProx):
+    """prox/scaled_zone.cc:123-279: projection of (v, s) onto {(x, t): f(x) <= t}.  The
+    reference finds the multiplier lam with a randomised 3-way-partition selection
+    (`random()`, :198); the multiplier itself is the unique root of
+        sum_i w_i^2 max(k_i - lam, 0) = s + lam ,   k_i = (|y_i| - M) / w_i ,  w = alpha or beta
+    which is computed here by sorting (any exact method gives the same number)."""
+
+    def init(self, arg):
+        VectorProx.init(self, arg)
+        self.alpha, self.beta, self.M, self.Cc = scaled_zone_params(arg.f, arg.data)
+
+    def apply_vector(self, ins):
+        v, s = ins[0], float(ins[1][0])
+        y = v - self.Cc
+        n = y.shape[0]
+        a, b, M = self.alpha[:n], self.beta[:n], self.M
+        w = np.where(y > 0, a, b)
+        act = (np.abs(y) > M) & (w != 0)
+        fval = float(np.sum(w[act] * (np.abs(y[act]) - M)))
+        if fval <= s:
+            return [v.copy(), np.array([s])]
+        k = (np.abs(y[act]) - M) / w[act]
+        w2 = w[act] ** 2
+        order = np.argsort(-k)
+        k, w2 = k[order], w2[order]
+        acc = np.cumsum(w2 * k) - s
+        div = np.cumsum(w2) + 1.0
+        lam_c = acc / div  # candidate with the j+1 largest keys active
+        nxt = np.append(k[1:], -np.inf)
+        j = np.nonzero((lam_c < k) & (lam_c >= nxt))[0][0]
+        lam = float(lam_c[j])
+        x = apply_scaled_zone(self.alpha, self.beta, M, self.Cc, np.full(n, lam), v)
+        return [x, np.array([s + lam])]
+
+
 class Norm2Prox(VectorProx):  # prox/norm_2.cc:4-19
     def apply_vector(self, ins):
         lam = self.lam_scalar()
@@ -1132,6 +1196,11 @@ class OrthoInvariantProx(VectorProx):  # prox/ortho_invariant.cc:7-116 (non-epig
 
 
 _PROX_REGISTRY = {
+    (ProxFunction.SUM_SQUARE, True): SumSquareEpigraph,
+    (ProxFunction.NORM_1, True): ScaledZoneEpigraph,
+    (ProxFunction.SUM_DEADZONE, True): ScaledZoneEpigraph,
+    (ProxFunction.SUM_HINGE, True): ScaledZoneEpigraph,
+    (ProxFunction.SUM_QUANTILE, True): ScaledZoneEpigraph,
     (ProxFunction.NORM_1, False): ScaledZoneProx,
     (ProxFunction.SUM_DEADZONE, False): ScaledZoneProx,
     (ProxFunction.SUM_HINGE, False): ScaledZoneProx,

@@ -557,3 +557,35 @@ def test_warm_start_reuses_factorisation(solve_mod, dtype):
     tol = dict(rtol=1e-7, atol=1e-9) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
     for k in x2:
         np.testing.assert_allclose(np.frombuffer(x2[k]), xo(k), err_msg=k, **tol)
+
+
+@pytest.mark.parametrize("kind", ["norm_1", "deadzone", "hinge", "quantile", "sum_square", "inside"])
+def test_epigraph_projections(solve_mod, dtype, kind):
+    """Epigraph operators (reference prox_test.py:232-246: NORM_1 / SUM_DEADZONE / SUM_HINGE /
+    SUM_QUANTILE / SUM_SQUARE epigraphs): projection of (v, s) onto {f(x) <= t}."""
+    n = 50
+    for trial in range(3):
+        rng = np.random.RandomState(trial + 17)
+        x = ir.variable(n, 1, "var:x")
+        t = ir.variable(1, 1, "var:t")
+        v, s = rng.randn(n), 0.5 * rng.randn()
+        kw = {}
+        if kind in ("norm_1", "inside"):
+            typ = ProxFunction.NORM_1
+            if kind == "inside":
+                s = float(np.abs(v).sum()) + 1.0
+        elif kind == "deadzone":
+            typ, kw = ProxFunction.SUM_DEADZONE, dict(scaled_zone_params=wire.ProxScaledZoneParams(m=0.3))
+        elif kind == "hinge":
+            typ = ProxFunction.SUM_HINGE
+        elif kind == "quantile":
+            qa, qb = ir.constant(np.full(n, 0.7)), ir.constant(np.full(n, 1.6))
+            data = dict(qa.data)
+            data.update(qb.data)
+            typ, kw = ProxFunction.SUM_QUANTILE, dict(
+                data=data, scaled_zone_params=wire.ProxScaledZoneParams(alpha_expr=qa.proto, beta_expr=qb.proto))
+        else:
+            typ = ProxFunction.SUM_SQUARE
+        expr = ir.prox(typ, x, t, epigraph=True, **kw)
+        tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=3e-4, atol=3e-5)
+        run_prox(solve_mod, expr, 1.0, {"var:x": v, "var:t": np.array([s])}, tol)

@@ -165,3 +165,25 @@ def test_nuclear_norm():  # prox_test.py:190
         U, s, Vt = np.linalg.svd(V, full_matrices=False)
         want = (U * np.maximum(s - lam, 0)) @ Vt
         np.testing.assert_allclose(got.reshape((m, n), order="F"), want, atol=1e-7)
+
+
+@pytest.mark.parametrize("kind", ["norm_1", "hinge", "sum_square"])
+def test_epigraph_projection_vs_constrained_solve(kind):
+    """prox_test.py:232-246 epigraph cases: eval_prox of an epigraph operator is the Euclidean
+    projection of (v, s) onto {(x, t): f(x) <= t}; checked against SLSQP."""
+    n = 8
+    rng = np.random.RandomState(3)
+    typ, f = {"norm_1": (ProxFunction.NORM_1, lambda z: np.abs(z).sum()),
+              "hinge": (ProxFunction.SUM_HINGE, lambda z: np.maximum(z, 0).sum()),
+              "sum_square": (ProxFunction.SUM_SQUARE, lambda z: (z * z).sum())}[kind]
+    x, t = ir.variable(n, 1, "var:x"), ir.variable(1, 1, "var:t")
+    for _ in range(3):
+        v, s = rng.randn(n), 0.5 * rng.randn()
+        got = eval_prox(ir.prox(typ, x, t, epigraph=True), 1.0, {"var:x": v, "var:t": [s]})
+        obj = lambda z: 0.5 * np.sum((z[:n] - v) ** 2) + 0.5 * (z[n] - s) ** 2
+        cons = {"type": "ineq", "fun": lambda z: z[n] - f(z[:n])}
+        z0 = np.concatenate([0.1 * v, [f(0.1 * v) + 1]])
+        r = optimize.minimize(obj, z0, constraints=[cons], method="SLSQP", options=dict(ftol=1e-14, maxiter=500))
+        np.testing.assert_allclose(got["var:x"], r.x[:n], atol=2e-4)
+        np.testing.assert_allclose(got["var:t"][0], r.x[n], atol=2e-4)
+        assert f(got["var:x"]) <= got["var:t"][0] + 1e-9
