@@ -213,6 +213,31 @@ BlockMatrix BlockMatrix::RightIdentity() const {
   return C;
 }
 
+namespace {
+// Sum over ranks of a partial product block.  Dense: the buffer.  Kronecker with one scalar
+// factor (kron(I_k, X_g^T X_g), the multi-response Gram): the dense factor - the scalar factor is
+// the same on every rank.
+LinearMap AllReduceMap(const LinearMap& P, const std::string& r, const std::string& k,
+                       const std::string& c) {
+  Comm* comm = Runtime::Get().comm();
+  if (P.impl().type() == DENSE_MATRIX) {
+    const auto& D = static_cast<const DenseMatrixImpl&>(P.impl());
+    DVec buf = D.Materialize(true);
+    comm->AllReduceSum(buf);
+    return LinearMap::Dense(buf, D.m(), D.n());
+  }
+  if (P.impl().type() == KRONECKER_PRODUCT) {
+    const auto& K = static_cast<const KroneckerProductImpl&>(P.impl());
+    const bool a_s = K.A().impl().type() == SCALAR_MATRIX, b_s = K.B().impl().type() == SCALAR_MATRIX;
+    if (a_s && K.B().impl().type() == DENSE_MATRIX) return LinearMap::Kronecker(K.A(), AllReduceMap(K.B(), r, k, c));
+    if (b_s && K.A().impl().type() == DENSE_MATRIX) return LinearMap::Kronecker(AllReduceMap(K.A(), r, k, c), K.B());
+  }
+  EPS_FATAL("sharded contraction (" << r << "," << k << ")*(" << k << "," << c
+                                    << ") has a type that cannot be summed over ranks: "
+                                    << P.impl().DebugString());
+}
+}  // namespace
+
 BlockMatrix operator*(const BlockMatrix& A, const BlockMatrix& B) {  // block_matrix.cc:102-127
   BlockMatrix C;
   for (const auto& bcol : B.data_) {
@@ -225,13 +250,7 @@ BlockMatrix operator*(const BlockMatrix& A, const BlockMatrix& B) {  // block_ma
         const ShardSpec& sh = ShardSpec::Get();
         if (sh.active() && sh.IsSharded(b.first) && !sh.IsSharded(a.first) &&
             !sh.IsSharded(bcol.first)) {
-          EPS_CHECK_MSG(P.impl().type() == DENSE_MATRIX,
-                        "sharded contraction (" << a.first << "," << b.first << ")*(" << b.first
-                                                << "," << bcol.first << ") must be dense");
-          const auto& D = static_cast<const DenseMatrixImpl&>(P.impl());
-          DVec buf = D.Materialize(true);
-          Runtime::Get().comm()->AllReduceSum(buf);
-          P = LinearMap::Dense(buf, D.m(), D.n());
+          P = AllReduceMap(P, a.first, b.first, bcol.first);
         }
         C.InsertOrAdd(a.first, bcol.first, P);
       }
@@ -367,13 +386,19 @@ uint64_t ComputeFill(const BlockMatrix& A, const std::string& k) {  // :11-48
     ImplType aik = ComputeType(A(i, k).impl().type(), A(k, k).impl().type());
     for (const std::string& j : keys) {
       ImplType type = ComputeType(aik, A(j, k).impl().type());
-      // Sharded solve: eliminating k must not create a non-elementwise block between two
-      // sharded keys - that block would couple the ranks' slices (and the local slice sizes
-      // would otherwise steer the ordering away from the single-GPU one).
-      if (sharded_solve && sh.IsSharded(i) && sh.IsSharded(j) && type != SCALAR_MATRIX &&
-          type != DIAGONAL_MATRIX)
+      // Sharded solve: each rank holds its own slice of every sharded key, and all maps between
+      // sharded keys are block-local by construction of the per-rank problem.  Eliminating a
+      // REPLICATED key k would connect the slices of two sharded keys through it (a coupling
+      // across ranks that no rank can form locally, e.g. A_g^T A_h), so that order is refused;
+      // it also keeps the local slice sizes from steering the order away from the single-GPU one.
+      if (sharded_solve && !sh.IsSharded(k) && sh.IsSharded(i) && sh.IsSharded(j))
         return kFillForbidden;
-      fill += Nonzeros(type, A(i, k).impl().m(), A(j, k).impl().m());
+      uint64_t mi = A(i, k).impl().m(), mj = A(j, k).impl().m();
+      if (sharded_solve) {  // sizes every rank agrees on
+        if (sh.IsSharded(i) && sh.global_dim(i)) mi = sh.global_dim(i);
+        if (sh.IsSharded(j) && sh.global_dim(j)) mj = sh.global_dim(j);
+      }
+      fill += Nonzeros(type, mi, mj);
     }
   }
   return fill;
@@ -451,7 +476,30 @@ BlockVector BackSub(const BlockMatrix& LT, const std::vector<std::string>& keys,
   return Substitute(LT, keys.rbegin(), keys.rend(), std::move(b));  // :103-117
 }
 
+namespace {
+// One small all-reduce: the global size of every sharded key of A (same key order on all ranks).
+void RegisterGlobalDims(const BlockMatrix& A) {
+  ShardSpec& sh = ShardSpec::Get();
+  if (!sh.active()) return;
+  std::map<std::string, double> dims;
+  for (const auto& c : A.data()) {
+    if (sh.IsSharded(c.first)) dims[c.first] = c.second.begin()->second.impl().n();
+    for (const auto& r : c.second)
+      if (sh.IsSharded(r.first)) dims[r.first] = r.second.impl().m();
+  }
+  if (dims.empty()) return;
+  std::vector<double> loc;
+  for (const auto& kv : dims) loc.push_back(kv.second);
+  DVec d = DVec::FromHost(loc.data(), static_cast<int64_t>(loc.size()), F64);
+  Runtime::Get().comm()->AllReduceSum(d);
+  std::vector<double> g = d.ToHost();
+  size_t i = 0;
+  for (const auto& kv : dims) sh.set_global_dim(kv.first, static_cast<int64_t>(g[i++] + 0.5));
+}
+}  // namespace
+
 void BlockCholesky::Compute(BlockMatrix A) {  // :119-133
+  RegisterGlobalDims(A);
   const size_t n_cols = A.col_keys().size();
   for (size_t i = 0; i < n_cols; ++i) {
     std::string key = NextKey(A);

@@ -13,6 +13,7 @@
 // the collective through gloo.
 #pragma once
 
+#include <map>
 #include <set>
 #include <string>
 
@@ -54,10 +55,18 @@ class ShardSpec {
   // operator's Init / Apply by LocalShardScope.
   void set_local(std::set<std::string> local) { local_ = std::move(local); }
   const std::set<std::string>& local() const { return local_; }
+  // Global (summed over ranks) size of a sharded key, so that size-driven decisions (the fill
+  // model of the block elimination) are identical on every rank.  0 = unknown.
+  void set_global_dim(const std::string& key, int64_t d) { global_dim_[key] = d; }
+  int64_t global_dim(const std::string& key) const {
+    auto it = global_dim_.find(key);
+    return it == global_dim_.end() ? 0 : it->second;
+  }
 
  private:
   std::set<std::string> keys_;
   std::set<std::string> local_;
+  std::map<std::string, int64_t> global_dim_;
 };
 
 struct LocalShardScope {

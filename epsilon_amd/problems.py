@@ -141,7 +141,7 @@ def multiclass_hinge_data(m, nf, k, seed=0):
     return X, Y
 
 
-def multiclass_hinge(X, Y, lam):
+def multiclass_hinge(X, Y, lam, c_vec=None):
     """Compiled form of sum_i max_j (X Theta + 1 - Y)_ij - <X^T Y, Theta> + lam||Theta||^2
     (functions.py:36-40) as printed at docs/notebooks/mnist.rst:118-129:
 
@@ -157,7 +157,8 @@ def multiclass_hinge(X, Y, lam):
     f0 = ir.prox(ProxFunction.AFFINE,
                  ir.linear_map(ir.dense_matrix(np.ones((1, m))), t), alpha=1.0)
     f1 = ir.prox(ProxFunction.NON_NEGATIVE, y, alpha=1.0)
-    c_vec = -(X.T.dot(Y)).reshape(1, -1, order="F")
+    if c_vec is None:  # a sample-sharded rank passes the GLOBAL -X^T Y here
+        c_vec = -(X.T.dot(Y)).reshape(1, -1, order="F")
     f2 = ir.prox(ProxFunction.AFFINE, ir.linear_map(ir.dense_matrix(c_vec), Z), alpha=1.0)
     f3 = ir.prox(ProxFunction.SUM_SQUARE, W, alpha=lam)
     ones_k = ir.dense_matrix(np.ones((1, k)))

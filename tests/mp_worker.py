@@ -37,6 +37,30 @@ def main():
         dist.all_reduce(t)
         return t.numpy()
 
+    if mode == "hip_mnist":
+        # BASELINE.json configs[3] shape: multiclass hinge, SAMPLES sharded over the ranks
+        from epsilon_amd import _solve
+        k, nf = 3, n
+        X, Y = problems.multiclass_hinge_data(m, nf, k, seed=seed)
+        lo, hi = edist.column_range(m, rank, world, align=1)
+        c_vec = -(X.T.dot(Y)).reshape(1, -1, order="F")
+        _solve.set_option("dtype", os.environ.get("EPS_TEST_DTYPE", "f64"))
+        edist.init_comm(rank, world, backend="host")
+        prob, _ = problems.multiclass_hinge(X[lo:hi], Y[lo:hi], 0.1, c_vec=c_vec)
+        _solve.shard_keys(["max_entries:t", "non_negative:y", "constraint:0"])
+        params = wire.SolverParams(max_iterations=max_iter)
+        st, x = _solve.solve(prob.SerializeToString(), [], params.SerializeToString(),
+                             prob.expression_data())
+        S = wire.SolverStatus.FromString(st)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+                 x0=np.frombuffer(x["max_entries:t"]), x1=np.frombuffer(x["var:Theta"]), lo=lo, hi=hi,
+                 status=np.array([S.num_iterations, S.residuals.r_norm, S.residuals.s_norm,
+                                  S.residuals.epsilon_primal, S.residuals.epsilon_dual]),
+                 state=S.state)
+        _solve.comm_shutdown()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "oracle":
         # unrolled compiled-lasso sweep on this rank's column slab
         G = allreduce(Ag.dot(Ag.T))                      # Gram: one all-reduce at Init

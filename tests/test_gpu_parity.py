@@ -589,3 +589,25 @@ def test_epigraph_projections(solve_mod, dtype, kind):
         expr = ir.prox(typ, x, t, epigraph=True, **kw)
         tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=3e-4, atol=3e-5)
         run_prox(solve_mod, expr, 1.0, {"var:x": v, "var:t": np.array([s])}, tol)
+
+
+def test_sample_sharded_multiclass_hinge(solve_mod, tmp_path):
+    """BASELINE.json configs[3] shape: multiclass hinge with the SAMPLES sharded over 2 ranks
+    (t, y and the big constraint row are sharded; Theta is replicated).  The contraction
+    kron(I_k, X_g^T X_g) is summed over ranks as a Kronecker factor, the X^T(.) products of the
+    forward substitution as vectors; iterates must equal the single-process oracle."""
+    from tests import mp_util
+    m, nf = 40, 8
+    t_all, theta_parts, status, parts = mp_util.run_ranks(2, "hip_mnist", str(tmp_path), m, nf, seed=0,
+                                                          max_iter=40, env_extra={"EPS_TEST_DTYPE": "f64"})
+    X, Y = problems.multiclass_hinge_data(m, nf, 3, seed=0)
+    prob, info = problems.multiclass_hinge(X, Y, lam=0.1)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams(max_iterations=40).SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    for s_, p in zip(status, parts):
+        assert int(s_[0]) == S.num_iterations and int(p["state"]) == S.state
+        np.testing.assert_allclose(s_[1:], [S.residuals.r_norm, S.residuals.s_norm,
+                                            S.residuals.epsilon_primal, S.residuals.epsilon_dual], rtol=1e-7)
+        np.testing.assert_allclose(p["x1"], np.frombuffer(x["var:Theta"]), rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(t_all, np.frombuffer(x["max_entries:t"]), rtol=1e-7, atol=1e-9)
