@@ -226,6 +226,14 @@ LinearMap AllReduceMap(const LinearMap& P, const std::string& r, const std::stri
     comm->AllReduceSum(buf);
     return LinearMap::Dense(buf, D.m(), D.n());
   }
+  if (P.impl().type() == SPARSE_MATRIX) {
+    // per-rank sparsity patterns differ: the sum is formed densely (the block is replicated,
+    // hence small next to the sharded data)
+    auto D = ToDense(P.impl(), MapDType(P.impl(), CurrentDType()));
+    DVec buf = D->data();
+    comm->AllReduceSum(buf);
+    return LinearMap::Dense(buf, D->m(), D->n());
+  }
   if (P.impl().type() == KRONECKER_PRODUCT) {
     const auto& K = static_cast<const KroneckerProductImpl&>(P.impl());
     const bool a_s = K.A().impl().type() == SCALAR_MATRIX, b_s = K.B().impl().type() == SCALAR_MATRIX;

@@ -5,6 +5,7 @@
 #include <sstream>
 
 #include "kernels.h"
+#include "sparse.h"
 
 namespace eps {
 
@@ -158,6 +159,7 @@ DType MapDType(const LinearMapImpl& A, DType fallback) {
   switch (A.type()) {
     case DENSE_MATRIX: return static_cast<const DenseMatrixImpl&>(A).dtype();
     case DIAGONAL_MATRIX: return static_cast<const DiagonalMatrixImpl&>(A).dtype();
+    case SPARSE_MATRIX: return static_cast<const SparseMatrixImpl&>(A).dtype();
     case KRONECKER_PRODUCT: {
       const auto& K = static_cast<const KroneckerProductImpl&>(A);
       return MapDType(K.A().impl(), MapDType(K.B().impl(), fallback));
@@ -400,6 +402,12 @@ std::shared_ptr<const DenseMatrixImpl> ToDense(const LinearMapImpl& A, DType dt)
       k::KronDense(W, DA->data(), DA->rows(), DA->cols(), DB->data(), DB->rows(), DB->cols());
       return std::make_shared<DenseMatrixImpl>(W, m, n, false, 1.0);
     }
+    case SPARSE_MATRIX: {
+      const auto& S = static_cast<const SparseMatrixImpl&>(A);
+      DVec W = DVec::Zeros(m * n, S.dtype());
+      k::ScatterAddCsc(S.csr_of_transpose(), 1.0, W);
+      return std::make_shared<DenseMatrixImpl>(W, m, n, false, 1.0);
+    }
     default:
       EPS_FATAL("ToDense: unsupported type " << ImplTypeName(A.type()));
   }
@@ -456,10 +464,41 @@ ImplPtr MultiplyScalarKron(const ScalarMatrixImpl& S, const KroneckerProductImpl
                                                 LinearMap(Multiply(S2, K.B().impl())));
 }
 
+// Sparse result formed from the operands' host CSC structure (reference: Eigen sparse
+// expressions on AsSparse() forms, linear_map_multiply.cc:79-110,119-153,208-241).
+ImplPtr MultiplyViaSparse(const LinearMapImpl& L, const LinearMapImpl& R) {
+  return std::make_shared<SparseMatrixImpl>(CscMultiply(AsSparseHost(L), AsSparseHost(R)),
+                                            PairDType(L, R));
+}
+
+ImplPtr MultiplyDenseSparse(const DenseMatrixImpl& A, const SparseMatrixImpl& S) {
+  // reference :39-45 (Dense result).  Output column j is a sparse combination of A's columns.
+  DVec Am = A.Materialize(false);
+  DVec C = DVec::Empty(A.m() * S.n(), A.dtype());
+  k::DenseSpmmCsc(S.csr_of_transpose(), 1.0, Am, A.m(), A.m(), C);
+  return std::make_shared<DenseMatrixImpl>(C, A.m(), S.n(), false, 1.0);
+}
+
+ImplPtr MultiplySparseDense(const SparseMatrixImpl& S, const DenseMatrixImpl& B) {
+  // reference :71-77 (Dense result)
+  DVec Bm = B.Materialize(false);
+  DVec C = DVec::Empty(S.m() * B.n(), B.dtype());
+  k::SpmmCsrDense(S.csr(), 1.0, Bm, B.m(), B.n(), C);
+  return std::make_shared<DenseMatrixImpl>(C, S.m(), B.n(), false, 1.0);
+}
+
 ImplPtr Multiply(const LinearMapImpl& L, const LinearMapImpl& R) {
   EPS_CHECK_MSG(L.n() == R.m(), "multiply: A: " << L.DebugString() << "\nB: " << R.DebugString());
   const ImplType a = L.type(), b = R.type();
-  EPS_CHECK_MSG(a != SPARSE_MATRIX && b != SPARSE_MATRIX, "sparse linear maps are not supported");
+  if (a == SPARSE_MATRIX || b == SPARSE_MATRIX) {
+    if (a == DENSE_MATRIX)
+      return MultiplyDenseSparse(static_cast<const DenseMatrixImpl&>(L),
+                                 static_cast<const SparseMatrixImpl&>(R));
+    if (b == DENSE_MATRIX)
+      return MultiplySparseDense(static_cast<const SparseMatrixImpl&>(L),
+                                 static_cast<const DenseMatrixImpl&>(R));
+    return MultiplyViaSparse(L, R);
+  }
   if (a == SCALAR_MATRIX) {
     const auto& S = static_cast<const ScalarMatrixImpl&>(L);
     switch (b) {
@@ -517,10 +556,11 @@ ImplPtr Multiply(const LinearMapImpl& L, const LinearMapImpl& R) {
     if (C.A().impl().n() == D.A().impl().m() && C.B().impl().n() == D.B().impl().m())
       return std::make_shared<KroneckerProductImpl>(C.A() * D.A(), C.B() * D.B());
   }
-  // Dense x {Diagonal, Kronecker}, {Diagonal, Kronecker} x Dense (reference: Dense result) and
-  // the Diagonal / Kronecker mixtures (reference: Sparse result) are formed densely here; both
-  // count as m*n non-zeros in the fill model, so the elimination order is unchanged.
-  return MultiplyViaDense(L, R);
+  // Dense x {Diagonal, Kronecker}, {Diagonal, Kronecker} x Dense: Dense result (reference
+  // :47-69,112-118,200-207); the Diagonal / Kronecker mixtures: Sparse result (:143-153,
+  // :215-221,:240).
+  if (a == DENSE_MATRIX || b == DENSE_MATRIX) return MultiplyViaDense(L, R);
+  return MultiplyViaSparse(L, R);
 }
 
 // ---- add table (reference linear/linear_map_add.cc) -----------------------------------------------
@@ -534,6 +574,11 @@ ImplPtr AddViaDense(const LinearMapImpl& L, const LinearMapImpl& R) {
   DVec C = A->Materialize(true);
   k::Axpby(C, 1.0, B->Materialize(false), 1.0);
   return std::make_shared<DenseMatrixImpl>(C, L.m(), L.n(), false, 1.0);
+}
+
+ImplPtr AddViaSparse(const LinearMapImpl& L, const LinearMapImpl& R) {
+  return std::make_shared<SparseMatrixImpl>(CscAdd(AsSparseHost(L), AsSparseHost(R)),
+                                            PairDType(L, R));
 }
 
 ImplPtr AddScalarKron(const ScalarMatrixImpl& S, const KroneckerProductImpl& K) {
@@ -550,14 +595,23 @@ ImplPtr AddScalarKron(const ScalarMatrixImpl& S, const KroneckerProductImpl& K) 
     LinearMap S2 = LinearMap::Scalar(0, K.B().impl().n());
     return std::make_shared<KroneckerProductImpl>(S1 + K.A(), S2 + K.B());
   }
-  return AddViaDense(S, K);
+  return AddViaSparse(S, K);  // reference :186
 }
 
 ImplPtr Add(const LinearMapImpl& L, const LinearMapImpl& R) {
   EPS_CHECK_MSG(L.m() == R.m() && L.n() == R.n(),
                 "add: A: " << L.DebugString() << "\nB: " << R.DebugString());
   const ImplType a = L.type(), b = R.type();
-  EPS_CHECK_MSG(a != SPARSE_MATRIX && b != SPARSE_MATRIX, "sparse linear maps are not supported");
+  if (a == SPARSE_MATRIX || b == SPARSE_MATRIX) {
+    if (a == DENSE_MATRIX || b == DENSE_MATRIX) {  // reference :21-28,56-63 (Dense result)
+      const auto& D = static_cast<const DenseMatrixImpl&>(a == DENSE_MATRIX ? L : R);
+      const auto& S = static_cast<const SparseMatrixImpl&>(a == DENSE_MATRIX ? R : L);
+      DVec C = D.Materialize(true);
+      k::ScatterAddCsc(S.csr_of_transpose(), 1.0, C);
+      return std::make_shared<DenseMatrixImpl>(C, D.m(), D.n(), false, 1.0);
+    }
+    return AddViaSparse(L, R);  // reference :65-98
+  }
   if (a == SCALAR_MATRIX && b == SCALAR_MATRIX) {
     return std::make_shared<ScalarMatrixImpl>(
         L.n(), static_cast<const ScalarMatrixImpl&>(L).alpha() +
@@ -622,7 +676,7 @@ ImplPtr Add(const LinearMapImpl& L, const LinearMapImpl& R) {
     if (K1.A() == K2.A()) return std::make_shared<KroneckerProductImpl>(K1.A(), K1.B() + K2.B());
     if (K1.B() == K2.B()) return std::make_shared<KroneckerProductImpl>(K1.A() + K2.A(), K1.B());
   }
-  return AddViaDense(L, R);
+  return AddViaSparse(L, R);  // Diagonal + Kronecker, unmatched Kronecker sums (:129-138,:224)
 }
 
 }  // namespace
@@ -652,8 +706,13 @@ LinearMap BuildLinearMap(const pb::LinearMap& p, DataMap* data) {
     case pb::LinearMap::TRANSPOSE:
       EPS_CHECK(p.arg.size() == 1);
       return BuildLinearMap(p.arg[0], data).Transpose();
-    case pb::LinearMap::SPARSE_MATRIX:
-      EPS_FATAL("SPARSE_MATRIX linear maps are not supported by the HIP solver yet");
+    case pb::LinearMap::SPARSE_MATRIX: {
+      const pb::Constant& c = data->Resolve(p.constant);
+      const Blob& b = data->Get(c.data_location);
+      EPS_CHECK_MSG(b.kind == 0, "sparse constants must be host blobs");
+      return LinearMap(std::make_shared<SparseMatrixImpl>(CscFromBlob(c, b.ptr, b.len),
+                                                          data->dtype()));
+    }
     default:
       EPS_FATAL("No linear map function for type " << p.linear_map_type);
   }

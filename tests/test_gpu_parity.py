@@ -9,6 +9,7 @@ operands are exactly representable.
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from epsilon_amd import ir, problems, wire
 from epsilon_amd.wire import ProxFunction
@@ -65,12 +66,14 @@ def square_maps(rng, n=6):
         "scalar": ir.scalar(1.7, n),
         "kron": ir.kronecker_product(ir.dense_matrix(rng.randn(2, 2)), ir.dense_matrix(rng.randn(3, 3))),
         "kron_s": ir.kronecker_product(ir.dense_matrix(rng.randn(2, 2)), ir.scalar(0.5, 3)),
+        "sparse": ir.sparse_matrix(sp.random(n, n, density=0.4, random_state=rng, format="csc")),
+        "sparse_diag": ir.sparse_matrix(sp.diags(rng.randn(n)).tocsc()),
     }
 
 
 @pytest.mark.parametrize("op", ["+", "*"])
 def test_linear_map_algebra_tables(solve_mod, dtype, op):
-    """All pairings of {Dense, Diagonal, Scalar, Kronecker}: values vs dense math and result
+    """All pairings of {Dense, Sparse, Diagonal, Scalar, Kronecker}: values vs dense math and result
     *type* vs the oracle's restatement of the dispatch tables
     (reference linear/linear_map_test.cc:67-229)."""
     rng = np.random.RandomState(1)
@@ -83,9 +86,97 @@ def test_linear_map_algebra_tables(solve_mod, dtype, op):
             np.testing.assert_allclose(dense, OC.as_dense(), err_msg="%s %s %s" % (an, op, bn),
                                        **TOL[dtype])
             expect = OC.type
-            if expect == orc.SPARSE:
-                expect = orc.DENSE  # sparse results are formed densely here (same fill count)
             assert rtype == expect, "%s %s %s -> type %d, oracle %d" % (an, op, bn, rtype, expect)
+
+
+def sparse_maps(rng):
+    sel = sp.coo_matrix((np.ones(40), (np.arange(40), rng.permutation(300)[:40])), shape=(40, 300))
+    long_rows = sp.random(5, 9000, density=0.6, random_state=rng)
+    skew = sp.vstack([sp.random(200, 700, density=0.01, random_state=rng),
+                      sp.csr_matrix(rng.randn(1, 700))])
+    return {
+        "random": sp.random(300, 500, density=0.05, random_state=rng),
+        "selection": sel,                    # reference python/epopt/linear_map.py:81-92 (index)
+        "transpose_matrix": sp.coo_matrix(   # linear_map.py:125-134
+            (np.ones(12), (np.arange(12), np.tile(np.arange(4) * 3, 3) + np.repeat(np.arange(3), 4))),
+            shape=(12, 12)),
+        "empty_rows": sp.random(64, 33, density=0.02, random_state=rng),
+        "all_zero": sp.csc_matrix((7, 9)),
+        "long_rows": long_rows,
+        "skew": skew,
+        "wide_1row": sp.csr_matrix(rng.randn(1, 5000)),
+        "tall_1col": sp.csr_matrix(rng.randn(5000, 1)),
+    }
+
+
+@pytest.mark.parametrize("name", ["random", "selection", "transpose_matrix", "empty_rows",
+                                  "all_zero", "long_rows", "skew", "wide_1row", "tall_1col"])
+def test_sparse_map_apply_and_adjoint(solve_mod, dtype, name):
+    """reference linear/sparse_matrix_impl.h:25,27-29 (Eigen A_*x, A_.transpose()) through the
+    wire format of python/epopt/constant.py:18-28 (CSC indptr | indices | data)."""
+    rng = np.random.RandomState(3)
+    S = sparse_maps(rng)[name]
+    A = ir.sparse_matrix(S)
+    x = rng.randn(S.shape[1])
+    y = rng.randn(S.shape[0])
+    np.testing.assert_allclose(solve_mod.linear_map_apply(A, x), S.dot(x), **TOL[dtype])
+    np.testing.assert_allclose(solve_mod.linear_map_apply(A, y, transpose=True), S.T.dot(y),
+                               **TOL[dtype])
+    O = oracle_map(A)
+    np.testing.assert_allclose(O.apply(x), S.dot(x), rtol=1e-12, atol=1e-12)
+
+
+def test_sparse_products_with_dense_and_kronecker(solve_mod, dtype):
+    """Rectangular Sparse x Dense, Dense x Sparse (Dense results, linear_map_multiply.cc:39-45,
+    71-77) and Sparse x Kronecker (Sparse result, :103-110)."""
+    rng = np.random.RandomState(4)
+    S = sp.random(30, 45, density=0.1, random_state=rng)
+    D1 = rng.randn(45, 17)
+    D2 = rng.randn(11, 30)
+    rtype, dense = solve_mod.linear_map_binary("*", ir.sparse_matrix(S), ir.dense_matrix(D1))
+    assert rtype == orc.DENSE
+    np.testing.assert_allclose(dense, S.dot(D1), **TOL[dtype])
+    rtype, dense = solve_mod.linear_map_binary("*", ir.dense_matrix(D2), ir.sparse_matrix(S))
+    assert rtype == orc.DENSE
+    np.testing.assert_allclose(dense, D2.dot(S.toarray()), **TOL[dtype])
+    rtype, dense = solve_mod.linear_map_binary(
+        "*", ir.transpose(ir.dense_matrix(D2.T.copy())), ir.sparse_matrix(S))
+    np.testing.assert_allclose(dense, D2.dot(S.toarray()), **TOL[dtype])
+    K = ir.kronecker_product(ir.dense_matrix(rng.randn(9, 5)), ir.identity(5))
+    rtype, dense = solve_mod.linear_map_binary("*", ir.sparse_matrix(S), K)
+    assert rtype == orc.SPARSE
+    np.testing.assert_allclose(dense, S.dot(oracle_map(K).as_dense()), **TOL[dtype])
+
+
+def test_sparse_inverse(solve_mod, dtype):
+    """reference sparse_matrix_impl.cc:60-78: scalar-like -> scalar inverse, else dense."""
+    rng = np.random.RandomState(5)
+    inv = solve_mod.linear_map_inverse(ir.sparse_matrix(sp.identity(6, format="csc") * 4.0))
+    np.testing.assert_allclose(inv, np.eye(6) / 4.0, **TOL[dtype])
+    G = sp.random(40, 60, density=0.1, random_state=rng)
+    W = (G.dot(G.T) + sp.identity(40)).tocsc()
+    inv = solve_mod.linear_map_inverse(ir.sparse_matrix(W))
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(inv, np.linalg.inv(W.toarray()), **tol)
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_sparse_lasso_matches_oracle(solve_mod, dtype, solver):
+    """Lasso with a sparse design matrix: the SUM_SQUARE prox builds A A^T through the sparse
+    table entries and every sweep runs two SpMVs."""
+    rng = np.random.RandomState(6)
+    m, n = 60, 150
+    A = sp.random(m, n, density=0.15, random_state=rng, format="csc")
+    x0 = np.where(rng.rand(n) < 0.1, rng.randn(n), 0)
+    b = A.dot(x0) + 0.01 * rng.randn(m)
+    lam = 0.1 * np.abs(A.T.dot(b)).max()
+    prob = problems.lasso_ir(ir.sparse_matrix(A), ir.constant(b), lam, n)
+    params = wire.SolverParams(solver=solver, max_iterations=60, rel_tol=1e-3, abs_tol=1e-5)
+    sg, xg, so, xo = solve_both(solve_mod, prob, params)
+    assert sg.state == so.state and sg.num_iterations == so.num_iterations
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
 
 
 @pytest.mark.parametrize("n", [1, 5, 64, 65, 130, 300])
