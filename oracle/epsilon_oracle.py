@@ -868,6 +868,15 @@ class VectorProx(object):
         check(not self.elementwise)
         return self.lam
 
+    def lam_vec_for(self, v):
+        """lambda_vec() (vector_prox.cc:189-191) at the length of the argument it scales: the
+        reference returns the whole vector whatever slice is being processed; scalar lambda
+        promoted to the slice length is the well-defined case."""
+        if self.elementwise:
+            check(self.lam_vec.shape[0] == v.shape[0], "elementwise lambda with an axis")
+            return self.lam_vec
+        return np.full(v.shape[0], self.lam)
+
     def apply_vector(self, ins):
         raise NotImplementedError
 
@@ -1155,8 +1164,11 @@ class AffineProx(object):  # prox/affine.cc:8-49
         return self.chol.solve(self.g + v)
 
 
-class OrthoInvariantProx(VectorProx):  # prox/ortho_invariant.cc:7-116 (non-epigraph, non-symmetric)
+class OrthoInvariantProx(VectorProx):  # prox/ortho_invariant.cc:7-116
     eigen_prox_type = ProxFunction.NORM_1
+    symmetric_part = False
+    add_residual = False
+    epigraph = False
 
     def init(self, arg):
         VectorProx.init(self, arg)
@@ -1169,30 +1181,498 @@ class OrthoInvariantProx(VectorProx):  # prox/ortho_invariant.cc:7-116 (non-epig
         # eigenvalues of Y^T Y (:36-50); for m < n its parameter vectors are then indexed out of
         # bounds (undefined behaviour).  The well-defined reading - n entries - is used here.
         n = self.n_
-        self.alpha_ = 1.0 / math.sqrt(lam)
+        nargs = 2 if self.epigraph else 1
+        self.alpha_ = 1.0 if self.epigraph else 1.0 / math.sqrt(lam)
         f = ProxFunction(prox_function_type=self.eigen_prox_type, alpha=1.0,
                          arg_size=[wire.Size(dim=[n, 1])])
         H, A = AffineOperator(), AffineOperator()
-        H.A.set(arg_key(0), arg_key(0), LM.identity(n))
-        A.A.set(arg_key(0), arg_key(0), LM.scalar(self.alpha_, n))
-        self.eigen_prox = create_prox_operator(self.eigen_prox_type, False)
+        for i in range(nargs):
+            # the reference gives the epigraph's t argument n entries too (:88-92); only its
+            # size-agnostic scalar maps are used, so 1 entry is the same operator
+            ni = n if i == 0 else 1
+            H.A.set(arg_key(i), arg_key(i), LM.identity(ni))
+            A.A.set(arg_key(i), arg_key(i), LM.scalar(self.alpha_, ni))
+        self.eigen_prox = create_prox_operator(self.eigen_prox_type, self.epigraph)
         self.eigen_prox.init(ProxArg(f, {}, H, A))
 
     def apply_vector(self, ins):  # :13-73
         if self.eigen_prox is None:
-            self._init_eigen_prox(self.lam_scalar())
+            self._init_eigen_prox(1.0 if self.epigraph else self.lam_scalar())
         Y = ins[0].reshape((self.m_, self.n_), order="F")
-        G = Y.T @ Y + 1e-15 * np.eye(self.n_)
-        d, V = np.linalg.eigh(G)
-        d = np.sqrt(np.maximum(d, 0.0))
-        dinv = np.zeros_like(d)
-        nz = d != 0
-        dinv[nz] = 1.0 / d[nz]
-        U = Y @ V @ np.diag(dinv)
+        R = (Y - Y.T) / 2 if self.add_residual else None
+        if self.symmetric_part:
+            d, V = np.linalg.eigh((Y + Y.T) / 2)
+            U = V
+        else:
+            G = Y.T @ Y + 1e-15 * np.eye(self.n_)
+            d, V = np.linalg.eigh(G)
+            d = np.sqrt(np.maximum(d, 0.0))
+            dinv = np.zeros_like(d)
+            nz = d != 0
+            dinv[nz] = 1.0 / d[nz]
+            U = Y @ V @ np.diag(dinv)
+        if self.epigraph:  # :52-60,107-116
+            s = float(ins[1][0])
+            out = self.eigen_prox.apply(BlockVector({arg_key(0): d, arg_key(1): np.array([s])}))
+            X = U @ np.diag(out(arg_key(0))) @ V.T
+            return [X.reshape(-1, order="F"), np.array([float(out(arg_key(1))[0])])]
         inp = BlockVector({arg_key(0): self.alpha_ * d})  # :100-105
         x_tilde = self.eigen_prox.apply(inp)(arg_key(0))
         X = U @ np.diag(x_tilde) @ V.T
+        if self.add_residual:
+            X = X + R
+        elif self.symmetric_part:
+            X = (X + X.T) / 2
         return [X.reshape(-1, order="F")]
+
+
+def _ortho(eigen_type, symmetric=False, residual=False, epi=False):
+    return type("OrthoInvariant_%d_%d%d%d" % (eigen_type, symmetric, residual, epi),
+                (OrthoInvariantProx,),
+                dict(eigen_prox_type=eigen_type, symmetric_part=symmetric, add_residual=residual,
+                     epigraph=epi))
+
+
+# ---- sort-based vector operators -------------------------------------------------------------
+
+
+class MaxProx(VectorProx):  # prox/max.cc:7-43
+    def apply_vector(self, ins):
+        v, lam = ins[0], self.lam_scalar()
+        y = np.sort(v)[::-1]
+        t, acc, div = 0.0, -lam, 0.0
+        for yi in y:
+            if yi * div < acc:
+                break
+            acc += yi
+            div += 1
+            t = acc / div
+        return [np.minimum(v, t)]
+
+
+class MaxEpigraph(VectorProx):  # prox/max.cc:46-87
+    def apply_vector(self, ins):
+        v, s = ins[0], float(ins[1][0])
+        y = np.sort(v)[::-1]
+        if s >= y[0]:
+            return [v.copy(), np.array([s])]
+        delta, acc, div = 0.0, 0.0, 1.0
+        for yi in y:
+            if div * (yi - s) < acc:
+                break
+            acc += yi - s
+            div += 1
+            delta = acc / div
+        t = s + delta
+        return [v - np.maximum(0.0, v - t), np.array([t])]
+
+
+def apply_sum_largest(v, lam, k):  # prox/sum_largest.cc:17-62
+    n = v.shape[0]
+    y = np.sort(v)[::-1]
+    q, acc, inside, i, j = 0.0, -k * lam, 0, 0, 0
+    while i < n and j < n:
+        if y[i] * inside <= acc and (y[j] - lam) * inside <= acc:
+            break
+        if y[i] >= y[j] - lam:
+            acc += y[i]
+            inside += 1
+            i += 1
+        else:
+            acc += -y[j] + lam
+            inside -= 1
+            j += 1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = float(np.float64(acc) / np.float64(inside))  # inside == 0 -> +-inf as in C++
+    return v - np.maximum(0.0, np.minimum(lam, v - q))
+
+
+def eval_sum_largest(x, k):  # prox/sum_largest.cc:64-78
+    return float(np.sum(np.sort(x)[::-1][:k]))
+
+
+class SumLargestProx(VectorProx):
+    def init(self, arg):
+        VectorProx.init(self, arg)
+        self.k = arg.f.sum_largest_params.k
+
+    def apply_vector(self, ins):
+        return [apply_sum_largest(ins[0], self.lam_scalar(), self.k)]
+
+
+class SumLargestEpigraph(SumLargestProx):  # BisectionEpigraph, prox/newton.cc:239-288
+    def apply_vector(self, ins):
+        v, s = ins[0], float(ins[1][0])
+        if eval_sum_largest(v, self.k) <= s:
+            return [v.copy(), np.array([s])]
+        lam, eps = 1.0, 1e-5
+        upper, lower, upper_fixed = lam, 0.0, False
+        x = v
+        for _ in range(100):
+            x = apply_sum_largest(v, lam, self.k)
+            g = eval_sum_largest(x, self.k) - (lam + s)
+            if abs(g) <= eps:
+                return [x, np.array([lam + s])]
+            if g > 0 and not upper_fixed:
+                lam *= 2
+                upper = lam
+            elif g > 0:
+                lower = lam
+                lam = (lam + upper) / 2
+            else:
+                upper = lam
+                lam = (lam + lower) / 2
+                upper_fixed = True
+        # the reference leaves output 1 unset when the bisection runs out (:288)
+        return [x, np.array([lam + s])]
+
+
+class SecondOrderConeProx(object):  # prox/second_order_cone.cc:6-124
+    def init(self, arg):
+        f = arg.f
+        check(len(f.arg_size) == 2)
+        self.m_, self.n_ = f.arg_size[1].dim[0], f.arg_size[1].dim[1]
+        H, g = arg.H.A, arg.H.b
+        self.t_key = self.x_key = None
+        for col in H.col_keys():  # GetArgKeys :6-19
+            for row, _ in H.col(col):
+                if row == arg_key(0):
+                    self.t_key = col
+                elif row == arg_key(1):
+                    self.x_key = col
+                else:
+                    raise CheckError("Unknown row key " + row)
+        at = get_scalar(H.get(arg_key(0), self.t_key))
+        ax = get_scalar(H.get(arg_key(1), self.x_key))
+        # BlockVector::Get(key, n): zeros when the key is absent (block_vector.cc:57-63)
+        bt = g(arg_key(0)) if g.has_key(arg_key(0)) else np.zeros(self.m_)
+        bx = g(arg_key(1)) if g.has_key(arg_key(1)) else np.zeros(self.m_ * self.n_)
+        self.a = at / abs(ax)
+        self.bx = bx / ax
+        self.bt = bt / abs(ax)
+        A = arg.A.A  # InitConstraints :109-122
+        AT = A.T()
+        ATA = AT @ A
+        alphat = get_scalar(ATA.get(self.t_key, self.t_key))
+        alphax = get_scalar(ATA.get(self.x_key, self.x_key))
+        check(alphat == alphax, "A'A not scalar matrix")
+        D = BlockMatrix()
+        D.set(self.x_key, self.x_key, LM.scalar(1 / alphat, self.m_ * self.n_))
+        D.set(self.t_key, self.t_key, LM.scalar(1 / alphat, self.m_))
+        self.AT = D @ AT
+
+    def apply(self, v):  # :46-56
+        u = self.AT.apply(v)
+        X = (u(self.x_key) + self.bx).reshape((self.m_, self.n_), order="F")
+        t = u(self.t_key) + self.bt / self.a
+        beta = self.a
+        v_norm = np.sqrt(np.sum(X * X, axis=1))
+        beta2 = beta * beta
+        with np.errstate(divide="ignore", invalid="ignore"):
+            alpha = (1 / (beta2 + 1)) * (beta2 + beta * t / v_norm)
+        t = t.copy()
+        for i in range(self.m_):  # :60-77
+            if np.isnan(alpha[i]) or alpha[i] > 1:
+                alpha[i] = 1
+            elif alpha[i] < 0:
+                alpha[i] = 0
+                t[i] = 0
+            else:
+                t[i] = (1 / beta) * alpha[i] * v_norm[i]
+        X = alpha[:, None] * X
+        x = BlockVector()
+        x.set(self.x_key, X.reshape(-1, order="F") - self.bx)
+        x.set(self.t_key, t - self.bt / self.a)
+        return x
+
+
+# ---- smooth functions and the Newton family (prox/newton.{h,cc}) --------------------------------
+
+
+class SmoothFunction(object):  # newton.h:6-22
+    def proj_feasible(self, x):
+        return x
+
+
+class ElemwiseSmoothFunction(SmoothFunction):  # newton.h:24-34
+    def hess_inv(self, lam, x, v):
+        return v / (1.0 + lam * self.hessf(x))
+
+
+class SumExp(ElemwiseSmoothFunction):  # prox/sum_exp.cc:11-36
+    def eval(self, x):
+        return float(np.sum(np.exp(x)))
+
+    def gradf(self, x):
+        return np.exp(x)
+
+    hessf = gradf
+
+
+class Logistic(ElemwiseSmoothFunction):  # prox/sum_logistic.cc:8-33
+    def eval(self, x):
+        return float(np.sum(np.log(1 + np.exp(x))))
+
+    def gradf(self, x):
+        return np.exp(x) / (1 + np.exp(x))
+
+    def hessf(self, x):
+        return np.exp(x) / (1 + np.exp(x)) ** 2
+
+
+class NegativeEntropy(ElemwiseSmoothFunction):  # prox/sum_neg_entr.cc:11-42
+    def eval(self, x):
+        pos = x > 0
+        return float(np.sum(x[pos] * np.log(x[pos])))
+
+    def gradf(self, x):
+        return 1 + np.log(x)
+
+    def hessf(self, x):
+        return 1 / x
+
+    def proj_feasible(self, x):
+        return np.maximum(x, 1e-6)
+
+
+class InvPos(ElemwiseSmoothFunction):  # prox/sum_inv_pos.cc:11-39
+    def eval(self, x):
+        return float(np.sum(1 / x))
+
+    def gradf(self, x):
+        return -1 / (x * x)
+
+    def hessf(self, x):
+        return 2 / (x * x * x)
+
+    def proj_feasible(self, x):
+        return np.maximum(x, 1e-6)
+
+
+class LogSumExp(SmoothFunction):  # prox/log_sum_exp.cc:20-68
+    def eval(self, x):
+        mx = float(np.max(x))
+        return mx + math.log(float(np.sum(np.exp(x - mx))))
+
+    def gradf(self, x):
+        w = np.exp(x - np.max(x))
+        return w / np.sum(w)
+
+    def hess_inv(self, lam, x, v):
+        lam = float(np.atleast_1d(lam)[0])
+        w = self.gradf(x)
+        t = float(np.sum(w * w / (1 + lam * w)))
+        r = float(np.sum(v * w / (1 + lam * w)))
+        s = lam * r / (1 - lam * t)
+        return v / (1 + lam * w) + w / (1 + lam * w) * s
+
+
+def _prox_residual(f, lam, x, v):  # newton.cc:8-14
+    return x - v + lam * f.gradf(x)
+
+
+def apply_newton_prox(f, lam, v):  # newton.cc:49-103 (lam: vector or scalar)
+    n = v.shape[0]
+    lam = np.full(n, lam) if np.isscalar(lam) else lam
+    eps = max(1e-12, 1e-10 / n)
+    x = f.proj_feasible(v)
+    for _ in range(100):
+        gx = _prox_residual(f, lam, x, v)
+        dx = f.hess_inv(lam, x, gx)
+        beta, gamma, theta = 0.001, 0.5, 1.0
+        x_res = float(np.linalg.norm(gx))
+        while theta > eps:
+            nx = f.proj_feasible(x - theta * dx)
+            nx_res = float(np.linalg.norm(_prox_residual(f, lam, nx, v)))
+            if nx_res <= (1 - beta * theta) * x_res:
+                x, x_res = nx, nx_res
+                break
+            theta *= gamma
+        if x_res < eps:
+            break
+    return x
+
+
+def _make_newton_prox(fcls):
+    class _NewtonProx(VectorProx):  # newton.cc:105-112
+        def apply_vector(self, ins):
+            return [apply_newton_prox(fcls(), self.lam_vec_for(ins[0]), ins[0])]
+    return _NewtonProx
+
+
+def _epigraph_residual(f, lam, x, t, v, s):  # newton.cc:16-27
+    return np.concatenate([x - v + lam * f.gradf(x), [t - s - lam, f.eval(x) - t]])
+
+
+def _make_newton_epigraph(fcls):
+    class _NewtonEpigraph(VectorProx):  # newton.cc:114-194
+        def apply_vector(self, ins):
+            f = fcls()
+            v, s = ins[0], float(ins[1][0])
+            n = v.shape[0]
+            eps = max(1e-12, 1e-10 / n)
+            x = f.proj_feasible(v)
+            if float(np.linalg.norm(v - x)) < eps and f.eval(x) <= s:
+                return [v.copy(), np.array([s])]
+            t, lam = s, 1.0
+            for _ in range(100):
+                g = _epigraph_residual(f, lam, x, t, v, s)
+                nt_step = f.hess_inv(lam, x, g[:n])
+                nt_res = float(g[:n] @ nt_step)
+                scale = (-nt_res + g[n] + g[n + 1]) / (nt_res + 1)
+                step_x = (1 + scale) * nt_step
+                step_t = g[n] - scale
+                step_l = -scale
+                beta, gamma, theta = 0.001, 0.5, 1.0
+                x_res = float(np.linalg.norm(g))
+                while theta > eps:
+                    nx = f.proj_feasible(x - theta * step_x)
+                    nt = t - theta * step_t
+                    nlam = max(lam - theta * step_l, eps)
+                    nx_res = float(np.linalg.norm(_epigraph_residual(f, nlam, nx, nt, v, s)))
+                    if nx_res <= (1 - beta * theta) * x_res:
+                        x, t, lam, x_res = nx, nt, nlam, nx_res
+                        break
+                    theta *= gamma
+                if x_res < eps:
+                    break
+            return [x, np.array([t])]
+    return _NewtonEpigraph
+
+
+def _make_implicit_newton_epigraph(fcls):
+    class _ImplicitNewtonEpigraph(VectorProx):  # newton.cc:196-237
+        def apply_vector(self, ins):
+            f = fcls()
+            v, s = ins[0], float(ins[1][0])
+            x = f.proj_feasible(v)
+            if f.eval(x) <= s:
+                return [x, np.array([s])]
+            lam = 1.0
+            for _ in range(100):
+                x = apply_newton_prox(f, lam, v)
+                gx = f.gradf(x)
+                glam = f.eval(x) - lam - s
+                hlam = -float(f.hess_inv(lam, x, gx) @ gx) - 1
+                if abs(glam) < 1e-10:
+                    break
+                lam = lam - glam / hlam
+                if lam < 0:
+                    lam = 1e-6
+            return [apply_newton_prox(f, lam, v), np.array([s + lam])]
+    return _ImplicitNewtonEpigraph
+
+
+def apply_neg_log_prox(lam, v):  # prox/sum_neg_log.cc:9-24
+    z = np.sqrt(v * v + 4 * lam)
+    return np.where(v >= 0, (v + z) / 2, 2 * lam / (-v + z))
+
+
+class SumNegLogProx(VectorProx):  # prox/sum_neg_log.cc:27-38
+    def apply_vector(self, ins):
+        return [apply_neg_log_prox(self.lam_vec_for(ins[0]), ins[0])]
+
+
+class SumNegLogEpigraph(VectorProx):  # prox/sum_neg_log.cc:42-90
+    def apply_vector(self, ins):
+        v, s = ins[0], float(ins[1][0])
+        n = v.shape[0]
+        eps, lam = 1e-10, 1.0
+        for _ in range(1000):
+            z = np.sqrt(v * v + 4 * lam)
+            pos = v >= 0
+            g = -lam - s - float(np.sum(np.log((v[pos] + z[pos]) / 2))) \
+                + float(np.sum(np.log((-v[~pos] + z[~pos]) / (2 * lam))))
+            h = -1.0 - float(np.sum(1.0 / (v[pos] * (v[pos] + z[pos]) / 2 + 2 * lam))) \
+                - float(np.sum(1.0 / (v[~pos] * 2 * lam / (-v[~pos] + z[~pos]) + 2 * lam)))
+            if abs(g) <= eps:
+                break
+            if h >= -1e-10:
+                h = -1e-10
+            lam -= g / h
+            if lam <= 1e-10:
+                lam = 1e-10
+        return [apply_neg_log_prox(np.full(n, lam), v), np.array([s + lam])]
+
+
+def apply_kl_div_prox(lam, u, v):  # prox/sum_kl_div.cc:6-54
+    eps = 1e-13
+    n = u.shape[0]
+    x, y = np.zeros(n), np.zeros(n)
+    for i in range(n):
+        li, ui, vi = float(lam[i]), float(u[i]), float(v[i])
+        yhat = max((0.5 + li - vi) / li, eps)
+        if abs(ui) < eps * eps and abs(vi) < eps * eps:
+            x[i], y[i] = ui, vi
+            continue
+        for _ in range(1000):
+            f = li * yhat * yhat + (vi - li) * yhat - ui + li * math.log(yhat)
+            F = 2 * li * yhat + (vi - li) + li / yhat
+            res = f / F
+            if abs(res) < eps or (yhat <= eps * 2 and res > 0) or \
+                    (li * yhat + vi - li <= eps * 2 and res > 0):
+                break
+            yhat = yhat - res
+            if yhat < eps:
+                yhat = eps
+            if li * yhat + vi - li < eps:
+                yhat = (eps + li - vi) / li
+        y[i] = li * yhat + vi - li
+        x[i] = y[i] * yhat
+    return x, y
+
+
+class SumKLDivProx(VectorProx):  # prox/sum_kl_div.cc:56-69
+    def apply_vector(self, ins):
+        x, y = apply_kl_div_prox(self.lam_vec_for(ins[0]), ins[0], ins[1])
+        return [x, y]
+
+
+class SumKLDivEpigraph(VectorProx):  # prox/sum_kl_div.cc:71-126
+    def apply_vector(self, ins):
+        u, v, s = ins[0], ins[1], float(ins[2][0])
+        n = u.shape[0]
+        eps, lam = 1e-10, 1.0
+        for _ in range(100):
+            x, y = apply_kl_div_prox(np.full(n, lam), u, v)
+            glam, hlam = -s - lam, -1.0
+            for i in range(n):
+                glam += x[i] * math.log(x[i] / y[i]) - x[i] + y[i]
+                g = np.array([math.log(x[i] / y[i]), -x[i] / y[i] + 1])
+                h = np.eye(2) + lam * np.array([[1 / x[i], -1 / y[i]],
+                                                [-1 / y[i], x[i] / (y[i] * y[i])]])
+                hlam -= float(g @ np.linalg.solve(h, g))
+            if abs(glam) < eps or (lam <= eps * 2 and glam / hlam > 0):
+                break
+            lam = lam - glam / hlam
+            if lam < eps:
+                lam = eps
+        x, y = apply_kl_div_prox(np.full(n, lam), u, v)
+        return [x, y, np.array([s + lam])]
+
+
+class ExpEpigraph(VectorProx):  # prox/exp.cc:12-77 (elementwise: x, t and s are all vectors)
+    def apply_vector(self, ins):
+        v, s = ins[0], ins[1]
+        x, t, l = v.copy(), s.copy(), np.ones(v.shape[0])
+        eps = 1e-12
+        for _ in range(100):
+            ex = np.exp(x)
+            r0 = (x - v) + l * ex
+            r1 = t - s - l
+            r2 = ex - t
+            if max(np.max(np.abs(r0)), np.max(np.abs(r1)), np.max(np.abs(r2))) < eps:
+                break
+            h = 1 + l * ex
+            d = ex
+            dl = (-d * r0 + h * (r1 + r2)) / (d * d + h)
+            dx = -(d * dl + r0) / h
+            dt = dl - r1
+            x, t, l = x + dx, t + dt, l + dl
+        easy = np.exp(v) <= s
+        x[easy] = v[easy]
+        t[easy] = s[easy]
+        return [x, t]
 
 
 _PROX_REGISTRY = {
@@ -1213,6 +1693,32 @@ _PROX_REGISTRY = {
     (ProxFunction.AFFINE, False): AffineProx,
     (ProxFunction.CONSTANT, False): AffineProx,
     (ProxFunction.NORM_NUCLEAR, False): OrthoInvariantProx,
+    (ProxFunction.NORM_NUCLEAR, True): _ortho(ProxFunction.NORM_1, False, False, True),
+    (ProxFunction.LAMBDA_MAX, False): _ortho(ProxFunction.MAX, True),
+    (ProxFunction.LAMBDA_MAX, True): _ortho(ProxFunction.MAX, True, False, True),
+    (ProxFunction.NEG_LOG_DET, False): _ortho(ProxFunction.SUM_NEG_LOG, True),
+    (ProxFunction.NEG_LOG_DET, True): _ortho(ProxFunction.SUM_NEG_LOG, True, False, True),
+    (ProxFunction.SEMIDEFINITE, False): _ortho(ProxFunction.NON_NEGATIVE, True, True),
+    (ProxFunction.MAX, False): MaxProx,
+    (ProxFunction.MAX, True): MaxEpigraph,
+    (ProxFunction.SUM_LARGEST, False): SumLargestProx,
+    (ProxFunction.SUM_LARGEST, True): SumLargestEpigraph,
+    (ProxFunction.SECOND_ORDER_CONE, False): SecondOrderConeProx,
+    (ProxFunction.SUM_EXP, False): _make_newton_prox(SumExp),
+    (ProxFunction.SUM_EXP, True): _make_newton_epigraph(SumExp),
+    (ProxFunction.SUM_LOGISTIC, False): _make_newton_prox(Logistic),
+    (ProxFunction.SUM_LOGISTIC, True): _make_newton_epigraph(Logistic),
+    (ProxFunction.SUM_INV_POS, False): _make_newton_prox(InvPos),
+    (ProxFunction.SUM_INV_POS, True): _make_newton_epigraph(InvPos),
+    (ProxFunction.SUM_NEG_ENTR, False): _make_newton_prox(NegativeEntropy),
+    (ProxFunction.SUM_NEG_ENTR, True): _make_implicit_newton_epigraph(NegativeEntropy),
+    (ProxFunction.LOG_SUM_EXP, False): _make_newton_prox(LogSumExp),
+    (ProxFunction.LOG_SUM_EXP, True): _make_newton_epigraph(LogSumExp),
+    (ProxFunction.SUM_NEG_LOG, False): SumNegLogProx,
+    (ProxFunction.SUM_NEG_LOG, True): SumNegLogEpigraph,
+    (ProxFunction.SUM_KL_DIV, False): SumKLDivProx,
+    (ProxFunction.SUM_KL_DIV, True): SumKLDivEpigraph,
+    (ProxFunction.EXP, True): ExpEpigraph,
 }
 
 
