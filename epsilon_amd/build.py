@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libepsilon_hip.so")
 
-HOST_SOURCES = ["wire.cc", "device.cc", "comm.cc", "linear_map.cc", "sparse.cc", "block.cc", "affine.cc", "prox.cc",
+HOST_SOURCES = ["wire.cc", "device.cc", "comm.cc", "linear_map.cc", "sparse.cc", "block.cc", "affine.cc", "prox.cc", "prox_more.cc",
                 "admm.cc", "capi.cc"]
 # -ffp-contract=off for the elementwise / prox kernels: thresholds and projections must pick
 # the same branch and produce the same bits as a plain IEEE evaluation.
@@ -26,6 +26,7 @@ DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_gemm.hip", []),
                   ("kernels_factor.hip", []),
                   ("kernels_sparse.hip", []),
+                  ("kernels_segprox.hip", ["-ffp-contract=off"]),
                   ("kernels_svd.hip", ["-ffp-contract=off"]),
                   ("kernels_tv.hip", ["-ffp-contract=off"])]
 

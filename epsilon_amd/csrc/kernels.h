@@ -116,6 +116,35 @@ void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma);
 // W[:, j] *= xt[j] / sigma[j]   (0 where sigma[j] == 0, as ortho_invariant.cc:44-49)
 void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt);
 
+// ---- batched ("segmented") and Newton-family operators (kernels_segprox.hip) ------------------
+// A segment is one slice of the argument the reference's axis loop would visit
+// (prox/vector_prox.cc:150-177): entry p of segment s lives at s*seg_stride + p*elem_stride.
+struct Segs {
+  int64_t count = 1, len = 0, seg_stride = 0, elem_stride = 1;
+};
+void SegNorm2Shrink(const DVec& x, const DVec& v, double lam, const Segs& S);
+void SegMaxProx(const DVec& x, const DVec& v, double lam, const Segs& S);          // prox/max.cc:7-43
+void SegMaxEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, const Segs& S);
+void SegSumLargestProx(const DVec& x, const DVec& v, double lam, int k, const Segs& S);
+void SegSumLargestEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, int k,
+                           const Segs& S);
+// one second-order cone per segment: (x_s, t_s) = proj{||x|| <= beta t} (second_order_cone.cc:58-79)
+void SegSocProject(const DVec& x, const DVec& t, const DVec& v, const DVec& tin, double beta,
+                   const Segs& S);
+void SegLogSumExpProx(const DVec& x, const DVec& v, double lam, const Segs& S);
+void SegLogSumExpEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s,
+                          const Segs& S);
+enum SmoothFn { SMOOTH_EXP, SMOOTH_LOGISTIC, SMOOTH_NEG_ENTR, SMOOTH_INV_POS, SMOOTH_NEG_LOG };
+// elementwise argmin lam f(x) + 1/2 (x - v)^2 (prox/newton.cc:49-112, sum_neg_log.cc:9-24)
+void SmoothProx(SmoothFn fn, const DVec& x, const DVec& v, double lam, const DVec* lam_vec);
+void SegSmoothEpigraph(SmoothFn fn, const DVec& x, const DVec& t, const DVec& v, const DVec& s,
+                       const Segs& S);
+void KlDivProx(const DVec& x, const DVec& y, const DVec& u, const DVec& v, double lam,
+               const DVec* lam_vec);
+void SegKlDivEpigraph(const DVec& x, const DVec& y, const DVec& t, const DVec& u, const DVec& v,
+                      const DVec& s, const Segs& S);
+void ExpEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s);  // prox/exp.cc
+
 // reference prox/total_variation_1d.cc:21 (glmgen tf_dp): exact 1-D TV prox
 void Tv1d(const DVec& x, const DVec& v, double lam);
 int Tv1dLastLevels();  // depth of the level-set recursion of the last Tv1d call

@@ -70,6 +70,35 @@ bool GetDiagonalBM(const BlockMatrix& A, std::vector<double>* alpha) {  // vecto
 
 }  // namespace
 
+k::Segs SegsOf(const pb::ProxFunction& f, int arg, int64_t n) {
+  k::Segs S;
+  if (!f.has_axis) {
+    S.count = 1;
+    S.len = n;
+    S.seg_stride = n;
+    S.elem_stride = 1;
+    return S;
+  }
+  EPS_CHECK_MSG(static_cast<int>(f.arg_size.size()) > arg && f.arg_size[arg].dim.size() == 2,
+                "prox function with an axis needs arg_size for argument " << arg);
+  EPS_CHECK_MSG(f.axis == 0 || f.axis == 1, "axis must be 0 or 1");
+  const int64_t rows = f.arg_size[arg].dim[0], cols = f.arg_size[arg].dim[1];
+  EPS_CHECK_MSG(rows * cols == n, "argument " << arg << " has " << n << " entries, arg_size says "
+                                              << rows << " x " << cols);
+  if (f.axis == 0) {  // slices are columns
+    S.count = cols;
+    S.len = rows;
+    S.seg_stride = rows;
+    S.elem_stride = 1;
+  } else {  // slices are rows of the column-major argument
+    S.count = rows;
+    S.len = cols;
+    S.seg_stride = 1;
+    S.elem_stride = rows;
+  }
+  return S;
+}
+
 double VectorProxInput::lambda() const {
   EPS_CHECK_MSG(!elementwise_, "scalar lambda requested from an elementwise-scaled prox");
   return lambda_;
@@ -363,8 +392,13 @@ REGISTER_EPIGRAPH_OPERATOR(SUM_QUANTILE, ScaledZoneEpigraph);
 class Norm2Prox final : public VectorProx {
  protected:
   void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
-    EPS_CHECK_MSG(!input.prox_function().has_axis, "NORM_2 with an axis is not supported yet");
     const DVec& v = input.value_vec(0);
+    if (input.prox_function().has_axis) {  // one group per row / column (group lasso)
+      DVec x = DVec::Empty(v.n, v.dt);
+      k::SegNorm2Shrink(x, v, input.lambda(), SegsOf(input.prox_function(), 0, v.n));
+      output->set_value(0, x);
+      return;
+    }
     if (!normsq_) normsq_ = Runtime::Get().Alloc(sizeof(double));
     double* slot = static_cast<double*>(normsq_->p);
     k::SumSq(v, slot, false);
@@ -541,86 +575,6 @@ class AffineProx final : public ProxOperator {
 };
 REGISTER_PROX_OPERATOR(AFFINE, AffineProx);
 REGISTER_PROX_OPERATOR(CONSTANT, AffineProx);
-
-// ---- OrthoInvariantProx: F(X) = f(singular values) (reference prox/ortho_invariant.cc:7-116) ---------
-// Non-symmetric, non-epigraph form (NORM_NUCLEAR, reference prox/norm_nuclear.cc:3-8): SVD of
-// the matrix argument, the scalar prox `eigen_prox_type` applied to the singular values through
-// a nested ProxOperator with A = (1/sqrt(lambda)) I exactly as InitEigenProx does (:76-98), and
-// X = U diag(x~) V^T.  The SVD is a one-sided Jacobi on the device (kernels_svd.hip) instead
-// of eig(Y^T Y + 1e-15 I).
-
-class OrthoInvariantProx : public VectorProx {
- public:
-  explicit OrthoInvariantProx(int eigen_prox_type) : eigen_prox_type_(eigen_prox_type) {}
-
-  void Init(const ProxOperatorArg& arg) override {
-    VectorProx::Init(arg);
-    const pb::ProxFunction& f = arg.prox_function();
-    EPS_CHECK_MSG(!f.arg_size.empty() && f.arg_size[0].dim.size() == 2,
-                  "matrix prox needs arg_size");
-    m_ = f.arg_size[0].dim[0];
-    n_ = f.arg_size[0].dim[1];
-    dtype_ = arg.data_map()->dtype();
-    eigen_prox_.reset();
-  }
-
- protected:
-  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
-    if (!eigen_prox_) InitEigenProx(input.lambda());
-    const DVec& y = input.value_vec(0);
-    EPS_CHECK(y.n == m_ * n_);
-    DVec W = y.Clone();
-    DVec V = DVec::Empty(n_ * n_, y.dt);
-    k::JacobiSvd(W, m_, n_, V);
-    DVec sigma = DVec::Empty(n_, y.dt);
-    k::ColNorms(W, m_, n_, sigma);
-    // ApplyEigenProx (:100-105): input alpha*d, output is x~
-    BlockVector in;
-    DVec scaled = DVec::Empty(n_, y.dt);
-    k::Axpby(scaled, alpha_, sigma, 0.0);
-    in.Set(affine::arg_key(0), scaled);
-    BlockVector out = eigen_prox_->Apply(in);
-    const DVec& xt = out(affine::arg_key(0));
-    k::ColScaleByRatio(W, m_, n_, sigma, xt);
-    DVec X = DVec::Empty(m_ * n_, y.dt);
-    k::Gemm(false, true, m_, n_, n_, 1.0, W, m_, V, n_, 0.0, X, m_);
-    output->set_value(0, X);
-  }
-
- private:
-  void InitEigenProx(double lambda) {  // ortho_invariant.cc:76-98
-    alpha_ = 1 / std::sqrt(lambda);
-    eigen_f_ = pb::ProxFunction();
-    eigen_f_.prox_function_type = eigen_prox_type_;
-    eigen_f_.alpha = 1;
-    pb::Size sz;
-    sz.dim = {static_cast<int32_t>(n_), 1};
-    eigen_f_.arg_size.push_back(sz);
-    const std::string key = affine::arg_key(0);
-    eigen_H_ = AffineOperator();
-    eigen_A_ = AffineOperator();
-    eigen_H_.A(key, key) = LinearMap::Identity(n_);
-    eigen_A_.A(key, key) = LinearMap::Scalar(alpha_, n_);
-    eigen_data_.reset(new DataMap(dtype_));
-    eigen_prox_ = CreateProxOperator(eigen_prox_type_, false);
-    eigen_prox_->Init(ProxOperatorArg(eigen_f_, eigen_data_.get(), eigen_H_, eigen_A_));
-  }
-
-  int eigen_prox_type_;
-  int64_t m_ = 0, n_ = 0;
-  DType dtype_ = F32;
-  double alpha_ = 1;
-  pb::ProxFunction eigen_f_;
-  AffineOperator eigen_H_, eigen_A_;
-  std::unique_ptr<DataMap> eigen_data_;
-  std::unique_ptr<ProxOperator> eigen_prox_;
-};
-
-class NormNuclearProx final : public OrthoInvariantProx {
- public:
-  NormNuclearProx() : OrthoInvariantProx(pb::ProxFunction::NORM_1) {}
-};
-REGISTER_PROX_OPERATOR(NORM_NUCLEAR, NormNuclearProx);
 
 }  // namespace
 

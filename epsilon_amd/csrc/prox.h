@@ -13,6 +13,7 @@
 
 #include "affine.h"
 #include "block.h"
+#include "kernels.h"
 #include "wire.h"
 
 namespace eps {
@@ -74,6 +75,10 @@ template <class T> bool RegisterProxOperator(int type, bool epigraph) {
 
 // ---- VectorProx: prox with scalar / diagonal H and A reduced to a plain vector prox ------------
 // reference prox/vector_prox.{h,cc}
+
+// Slices of argument `arg` (n entries) the reference's axis loop visits (vector_prox.cc:150-177):
+// columns for axis 0, rows for axis 1, the whole argument when the function has no axis.
+k::Segs SegsOf(const pb::ProxFunction& f, int arg, int64_t n);
 
 class VectorProxInput {
  public:

@@ -1,0 +1,426 @@
+// Remaining proximal / epigraph operators of the reference's library:
+// sort-based vector functions, the smooth Newton family, log-sum-exp, KL divergence, the
+// second-order cone and the orthogonally invariant matrix functions.  Each class keeps the
+// reference's plugin interface (prox/prox.h:37-77) and cites the file it restates; the numeric
+// work is in kernels_segprox.hip / kernels_svd.hip.
+#include <cmath>
+
+#include "kernels.h"
+#include "prox.h"
+
+namespace eps {
+namespace {
+
+DVec NewLike(const DVec& v) { return DVec::Empty(v.n, v.dt); }
+
+// ---- MAX (reference prox/max.cc) ----------------------------------------------------------------
+
+class MaxProx final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = NewLike(v);
+    k::SegMaxProx(x, v, input.lambda(), SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+  }
+};
+REGISTER_PROX_OPERATOR(MAX, MaxProx);
+
+class MaxEpigraph final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    const DVec& s = input.value_vec(1);
+    DVec x = NewLike(v), t = NewLike(s);
+    k::SegMaxEpigraph(x, t, v, s, SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+    output->set_value(1, t);
+  }
+};
+REGISTER_EPIGRAPH_OPERATOR(MAX, MaxEpigraph);
+
+// ---- SUM_LARGEST (reference prox/sum_largest.cc; epigraph: BisectionEpigraph newton.cc:239-288) --
+
+class SumLargestProx final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = NewLike(v);
+    k::SegSumLargestProx(x, v, input.lambda(), input.prox_function().sum_largest_k,
+                         SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+  }
+};
+REGISTER_PROX_OPERATOR(SUM_LARGEST, SumLargestProx);
+
+class SumLargestEpigraph final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    const DVec& s = input.value_vec(1);
+    DVec x = NewLike(v), t = NewLike(s);
+    k::SegSumLargestEpigraph(x, t, v, s, input.prox_function().sum_largest_k,
+                             SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+    output->set_value(1, t);
+  }
+};
+REGISTER_EPIGRAPH_OPERATOR(SUM_LARGEST, SumLargestEpigraph);
+
+// ---- LOG_SUM_EXP (reference prox/log_sum_exp.cc) -----------------------------------------------------
+
+class LogSumExpProx final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = NewLike(v);
+    k::SegLogSumExpProx(x, v, input.lambda(), SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+  }
+};
+REGISTER_PROX_OPERATOR(LOG_SUM_EXP, LogSumExpProx);
+
+class LogSumExpEpigraph final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    const DVec& s = input.value_vec(1);
+    DVec x = NewLike(v), t = NewLike(s);
+    k::SegLogSumExpEpigraph(x, t, v, s, SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+    output->set_value(1, t);
+  }
+};
+REGISTER_EPIGRAPH_OPERATOR(LOG_SUM_EXP, LogSumExpEpigraph);
+
+// ---- smooth separable family (reference prox/newton.cc + sum_exp.cc, sum_logistic.cc,
+//      sum_neg_entr.cc, sum_inv_pos.cc, sum_neg_log.cc) --------------------------------------------------
+
+template <k::SmoothFn FN> class SmoothProxOp final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    DVec x = NewLike(v);
+    if (input.elementwise()) {
+      EPS_CHECK_MSG(input.lambda_vec().n == v.n, "elementwise lambda does not match the argument");
+      k::SmoothProx(FN, x, v, 0.0, &input.lambda_vec());
+    } else {
+      k::SmoothProx(FN, x, v, input.lambda(), nullptr);
+    }
+    output->set_value(0, x);
+  }
+};
+
+template <k::SmoothFn FN> class SmoothEpigraphOp final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    const DVec& s = input.value_vec(1);
+    DVec x = NewLike(v), t = NewLike(s);
+    k::SegSmoothEpigraph(FN, x, t, v, s, SegsOf(input.prox_function(), 0, v.n));
+    output->set_value(0, x);
+    output->set_value(1, t);
+  }
+};
+
+using SumExpProx = SmoothProxOp<k::SMOOTH_EXP>;
+using SumExpEpigraph = SmoothEpigraphOp<k::SMOOTH_EXP>;
+using SumLogisticProx = SmoothProxOp<k::SMOOTH_LOGISTIC>;
+using SumLogisticEpigraph = SmoothEpigraphOp<k::SMOOTH_LOGISTIC>;
+using SumNegEntrProx = SmoothProxOp<k::SMOOTH_NEG_ENTR>;
+using SumNegEntrEpigraph = SmoothEpigraphOp<k::SMOOTH_NEG_ENTR>;
+using SumInvPosProx = SmoothProxOp<k::SMOOTH_INV_POS>;
+using SumInvPosEpigraph = SmoothEpigraphOp<k::SMOOTH_INV_POS>;
+using SumNegLogProx = SmoothProxOp<k::SMOOTH_NEG_LOG>;
+using SumNegLogEpigraph = SmoothEpigraphOp<k::SMOOTH_NEG_LOG>;
+REGISTER_PROX_OPERATOR(SUM_EXP, SumExpProx);
+REGISTER_EPIGRAPH_OPERATOR(SUM_EXP, SumExpEpigraph);
+REGISTER_PROX_OPERATOR(SUM_LOGISTIC, SumLogisticProx);
+REGISTER_EPIGRAPH_OPERATOR(SUM_LOGISTIC, SumLogisticEpigraph);
+REGISTER_PROX_OPERATOR(SUM_NEG_ENTR, SumNegEntrProx);
+REGISTER_EPIGRAPH_OPERATOR(SUM_NEG_ENTR, SumNegEntrEpigraph);
+REGISTER_PROX_OPERATOR(SUM_INV_POS, SumInvPosProx);
+REGISTER_EPIGRAPH_OPERATOR(SUM_INV_POS, SumInvPosEpigraph);
+REGISTER_PROX_OPERATOR(SUM_NEG_LOG, SumNegLogProx);
+REGISTER_EPIGRAPH_OPERATOR(SUM_NEG_LOG, SumNegLogEpigraph);
+
+// ---- SUM_KL_DIV (reference prox/sum_kl_div.cc) ----------------------------------------------------------
+
+class SumKLDivProx final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& u = input.value_vec(0);
+    const DVec& v = input.value_vec(1);
+    DVec x = NewLike(u), y = NewLike(v);
+    if (input.elementwise()) {
+      // lambda_vec() covers both arguments (vector_prox.cc:108-116); the kernel wants the first
+      EPS_CHECK_MSG(input.lambda_vec().n >= u.n, "elementwise lambda shorter than the argument");
+      DVec lv = input.lambda_vec().Slice(0, u.n);
+      k::KlDivProx(x, y, u, v, 0.0, &lv);
+    } else {
+      k::KlDivProx(x, y, u, v, input.lambda(), nullptr);
+    }
+    output->set_value(0, x);
+    output->set_value(1, y);
+  }
+};
+REGISTER_PROX_OPERATOR(SUM_KL_DIV, SumKLDivProx);
+
+class SumKLDivEpigraph final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& u = input.value_vec(0);
+    const DVec& v = input.value_vec(1);
+    const DVec& s = input.value_vec(2);
+    DVec x = NewLike(u), y = NewLike(v), t = NewLike(s);
+    k::SegKlDivEpigraph(x, y, t, u, v, s, SegsOf(input.prox_function(), 0, u.n));
+    output->set_value(0, x);
+    output->set_value(1, y);
+    output->set_value(2, t);
+  }
+};
+REGISTER_EPIGRAPH_OPERATOR(SUM_KL_DIV, SumKLDivEpigraph);
+
+// ---- EXP epigraph, elementwise (reference prox/exp.cc) -----------------------------------------------
+
+class ExpEpigraph final : public VectorProx {
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    const DVec& v = input.value_vec(0);
+    const DVec& s = input.value_vec(1);
+    DVec x = NewLike(v), t = NewLike(s);
+    k::ExpEpigraph(x, t, v, s);
+    output->set_value(0, x);
+    output->set_value(1, t);
+  }
+};
+REGISTER_EPIGRAPH_OPERATOR(EXP, ExpEpigraph);
+
+// ---- SECOND_ORDER_CONE (reference prox/second_order_cone.cc:21-124) ------------------------------------
+// ||ax*X_i + bx||_2 <= at*t_i + bt_i for the rows X_i of the m x n argument; "t" is argument 0.
+
+class SecondOrderConeProx final : public ProxOperator {
+ public:
+  void Init(const ProxOperatorArg& arg) override {
+    const pb::ProxFunction& f = arg.prox_function();
+    EPS_CHECK_MSG(f.arg_size.size() == 2 && f.arg_size[1].dim.size() == 2,
+                  "SECOND_ORDER_CONE needs two sized arguments");
+    m_ = f.arg_size[1].dim[0];
+    n_ = f.arg_size[1].dim[1];
+    const DType dt = arg.data_map()->dtype();
+    // InitArgs (:90-107)
+    const BlockMatrix& H = arg.affine_arg().A;
+    for (const auto& col : H.data()) {  // GetArgKeys (:6-19)
+      for (const auto& row : col.second) {
+        if (row.first == affine::arg_key(0)) t_key_ = col.first;
+        else if (row.first == affine::arg_key(1)) x_key_ = col.first;
+        else EPS_FATAL("Unknown row key " << row.first);
+      }
+    }
+    EPS_CHECK_MSG(!t_key_.empty() && !x_key_.empty(), "SECOND_ORDER_CONE: missing argument");
+    const double at = GetScalar(H(affine::arg_key(0), t_key_));
+    const double ax = GetScalar(H(affine::arg_key(1), x_key_));
+    const BlockVector& g = arg.affine_arg().b;
+    a_ = at / std::fabs(ax);
+    // bx_ = g(arg 1) / ax ; bt_/a_ = g(arg 0) / |ax| / a_   (zeros when absent, block_vector.cc:62-67)
+    bx_ = DVec::Zeros(m_ * n_, dt);
+    if (g.has_key(affine::arg_key(1))) k::Axpby(bx_, 1 / ax, g(affine::arg_key(1)), 0.0);
+    bt_over_a_ = DVec::Zeros(m_, dt);
+    if (g.has_key(affine::arg_key(0)))
+      k::Axpby(bt_over_a_, 1 / std::fabs(ax) / a_, g(affine::arg_key(0)), 0.0);
+    // InitConstraints (:109-122): A'A must be one scalar
+    const BlockMatrix& A = arg.affine_constraint().A;
+    AT_ = A.Transpose();
+    BlockMatrix ATA = AT_ * A;
+    const double alphat = GetScalar(ATA(t_key_, t_key_));
+    const double alphax = GetScalar(ATA(x_key_, x_key_));
+    EPS_CHECK_MSG(alphat == alphax, "A'A not scalar matrix");
+    BlockMatrix D;
+    D(x_key_, x_key_) = LinearMap::Scalar(1 / alphat, m_ * n_);
+    D(t_key_, t_key_) = LinearMap::Scalar(1 / alphat, m_);
+    AT_ = D * AT_;
+  }
+
+  BlockVector Apply(const BlockVector& v) override {  // :46-56
+    BlockVector u = AT_ * v;
+    DVec X = u(x_key_).Clone();
+    k::Axpby(X, 1.0, bx_, 1.0);
+    DVec t = u(t_key_).Clone();
+    k::Axpby(t, 1.0, bt_over_a_, 1.0);
+    EPS_CHECK(X.n == m_ * n_ && t.n == m_);
+    k::Segs S;  // rows of the column-major m x n matrix
+    S.count = m_;
+    S.len = n_;
+    S.seg_stride = 1;
+    S.elem_stride = m_;
+    DVec Xo = NewLike(X), to = NewLike(t);
+    k::SegSocProject(Xo, to, X, t, a_, S);
+    k::Axpby(Xo, -1.0, bx_, 1.0);
+    k::Axpby(to, -1.0, bt_over_a_, 1.0);
+    BlockVector x;
+    x.Set(x_key_, Xo);
+    x.Set(t_key_, to);
+    return x;
+  }
+
+ private:
+  BlockMatrix AT_;
+  double a_ = 1;
+  DVec bx_, bt_over_a_;
+  std::string t_key_, x_key_;
+  int64_t m_ = 0, n_ = 0;
+};
+REGISTER_PROX_OPERATOR(SECOND_ORDER_CONE, SecondOrderConeProx);
+
+// ---- OrthoInvariantProx: F(X) = f(spectrum of X) (reference prox/ortho_invariant.{h,cc}) -----------
+// The reference diagonalises Y^T Y + 1e-15 I (singular values) or (Y + Y^T)/2 (eigenvalues) with
+// Eigen's SelfAdjointEigenSolver on the host and hands the spectrum to a nested vector prox.
+// Here both spectra come from the one-sided Jacobi SVD on the device (kernels_svd.hip); the
+// symmetric eigenproblem is solved as the SVD of the shifted matrix S + cI with c > ||S||_F,
+// which is positive definite, so its singular vectors ARE the eigenvectors and its singular
+// values the eigenvalues + c (no +-sigma ambiguity).
+
+class OrthoInvariantProx : public VectorProx {
+ public:
+  OrthoInvariantProx(int eigen_prox_type, bool symmetric_part = false, bool add_residual = false,
+                     bool epigraph = false)
+      : eigen_prox_type_(eigen_prox_type), symmetric_part_(symmetric_part),
+        add_residual_(add_residual), epigraph_(epigraph) {}
+
+  void Init(const ProxOperatorArg& arg) override {
+    VectorProx::Init(arg);
+    const pb::ProxFunction& f = arg.prox_function();
+    EPS_CHECK_MSG(!f.arg_size.empty() && f.arg_size[0].dim.size() == 2,
+                  "matrix prox needs arg_size");
+    m_ = f.arg_size[0].dim[0];
+    n_ = f.arg_size[0].dim[1];
+    EPS_CHECK_MSG(!symmetric_part_ || m_ == n_, "symmetric matrix function of a non-square argument");
+    dtype_ = arg.data_map()->dtype();
+    eigen_prox_.reset();
+  }
+
+ protected:
+  void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
+    if (!eigen_prox_) InitEigenProx(epigraph_ ? 1.0 : input.lambda());
+    const DVec& y = input.value_vec(0);
+    EPS_CHECK(y.n == m_ * n_);
+    DVec W, R;
+    double shift = 0;
+    if (symmetric_part_) {
+      W = DVec::Empty(y.n, y.dt);
+      k::MatCopy(true, n_, n_, 0.5, y, n_, W);  // W = Y^T / 2
+      if (add_residual_) {
+        R = DVec::Empty(y.n, y.dt);
+        k::Axpby(R, 0.5, y, 0.0);
+        k::Axpby(R, -1.0, W, 1.0);  // (Y - Y^T) / 2
+      }
+      k::Axpby(W, 0.5, y, 1.0);  // (Y + Y^T) / 2
+      Runtime& rt = Runtime::Get();
+      rt.ResetSlots();
+      const int slot = rt.NewSlot();
+      k::SumSq(W, rt.SlotPtr(slot), false);
+      rt.FetchSlots();
+      shift = std::sqrt(rt.SlotValue(slot)) * 1.0625 + 1e-300;
+      k::AddDiag(W, n_, n_, shift, nullptr);
+    } else {
+      W = y.Clone();
+    }
+    DVec V = DVec::Empty(n_ * n_, y.dt);
+    k::JacobiSvd(W, m_, n_, V);
+    DVec sigma = DVec::Empty(n_, y.dt);
+    k::ColNorms(W, m_, n_, sigma);
+    DVec d = sigma;
+    if (symmetric_part_) {
+      d = DVec::Full(n_, -shift, y.dt);
+      k::Axpby(d, 1.0, sigma, 1.0);
+    }
+    BlockVector in;
+    DVec xt, t;
+    if (epigraph_) {  // ApplyEigenEpigraph (:107-116)
+      in.Set(affine::arg_key(0), d);
+      in.Set(affine::arg_key(1), input.value_vec(1));
+      BlockVector out = eigen_prox_->Apply(in);
+      xt = out(affine::arg_key(0));
+      t = out(affine::arg_key(1));
+    } else {  // ApplyEigenProx (:100-105): input alpha*d
+      DVec scaled = DVec::Empty(n_, y.dt);
+      k::Axpby(scaled, alpha_, d, 0.0);
+      in.Set(affine::arg_key(0), scaled);
+      xt = eigen_prox_->Apply(in)(affine::arg_key(0));
+    }
+    k::ColScaleByRatio(W, m_, n_, sigma, xt);  // U diag(x~), U = W diag(1/sigma)
+    DVec X = DVec::Empty(m_ * n_, y.dt);
+    k::Gemm(false, true, m_, n_, n_, 1.0, W, m_, V, n_, 0.0, X, m_);
+    if (!epigraph_) {
+      if (add_residual_) {
+        k::Axpby(X, 1.0, R, 1.0);
+      } else if (symmetric_part_) {
+        DVec Xt = DVec::Empty(X.n, X.dt);
+        k::MatCopy(true, n_, n_, 0.5, X, n_, Xt);
+        k::Axpby(Xt, 0.5, X, 1.0);
+        X = Xt;
+      }
+    }
+    output->set_value(0, X);
+    if (epigraph_) output->set_value(1, t);
+  }
+
+ private:
+  void InitEigenProx(double lambda) {  // ortho_invariant.cc:76-98
+    // The reference sizes the nested prox with min(m, n) and feeds it n values (:36-50,:77); n is
+    // the well-defined reading.
+    const int num_args = epigraph_ ? 2 : 1;
+    alpha_ = epigraph_ ? 1.0 : 1 / std::sqrt(lambda);
+    eigen_f_ = pb::ProxFunction();
+    eigen_f_.prox_function_type = eigen_prox_type_;
+    eigen_f_.alpha = 1;
+    pb::Size sz;
+    sz.dim = {static_cast<int32_t>(n_), 1};
+    eigen_f_.arg_size.push_back(sz);
+    eigen_H_ = AffineOperator();
+    eigen_A_ = AffineOperator();
+    for (int i = 0; i < num_args; ++i) {
+      const std::string key = affine::arg_key(i);
+      const int64_t ni = i == 0 ? n_ : 1;
+      eigen_H_.A(key, key) = LinearMap::Identity(ni);
+      eigen_A_.A(key, key) = LinearMap::Scalar(alpha_, ni);
+    }
+    eigen_data_.reset(new DataMap(dtype_));
+    eigen_prox_ = CreateProxOperator(eigen_prox_type_, epigraph_);
+    eigen_prox_->Init(ProxOperatorArg(eigen_f_, eigen_data_.get(), eigen_H_, eigen_A_));
+  }
+
+  int eigen_prox_type_;
+  bool symmetric_part_, add_residual_, epigraph_;
+  int64_t m_ = 0, n_ = 0;
+  DType dtype_ = F32;
+  double alpha_ = 1;
+  pb::ProxFunction eigen_f_;
+  AffineOperator eigen_H_, eigen_A_;
+  std::unique_ptr<DataMap> eigen_data_;
+  std::unique_ptr<ProxOperator> eigen_prox_;
+};
+
+#define EPS_ORTHO_OPERATOR(NAME, ...)                         \
+  class NAME final : public OrthoInvariantProx {              \
+   public:                                                    \
+    NAME() : OrthoInvariantProx(__VA_ARGS__) {}               \
+  }
+
+EPS_ORTHO_OPERATOR(NormNuclearProx, pb::ProxFunction::NORM_1);                          // norm_nuclear.cc
+EPS_ORTHO_OPERATOR(NormNuclearEpigraph, pb::ProxFunction::NORM_1, false, false, true);
+EPS_ORTHO_OPERATOR(LambdaMaxProx, pb::ProxFunction::MAX, true);                         // lambda_max.cc
+EPS_ORTHO_OPERATOR(LambdaMaxEpigraph, pb::ProxFunction::MAX, true, false, true);
+EPS_ORTHO_OPERATOR(NegLogDetProx, pb::ProxFunction::SUM_NEG_LOG, true);                 // neg_log_det.cc
+EPS_ORTHO_OPERATOR(NegLogDetEpigraph, pb::ProxFunction::SUM_NEG_LOG, true, false, true);
+EPS_ORTHO_OPERATOR(SemidefiniteProx, pb::ProxFunction::NON_NEGATIVE, true, true);       // semidefinite.cc
+REGISTER_PROX_OPERATOR(NORM_NUCLEAR, NormNuclearProx);
+REGISTER_EPIGRAPH_OPERATOR(NORM_NUCLEAR, NormNuclearEpigraph);
+REGISTER_PROX_OPERATOR(LAMBDA_MAX, LambdaMaxProx);
+REGISTER_EPIGRAPH_OPERATOR(LAMBDA_MAX, LambdaMaxEpigraph);
+REGISTER_PROX_OPERATOR(NEG_LOG_DET, NegLogDetProx);
+REGISTER_EPIGRAPH_OPERATOR(NEG_LOG_DET, NegLogDetEpigraph);
+REGISTER_PROX_OPERATOR(SEMIDEFINITE, SemidefiniteProx);
+
+}  // namespace
+}  // namespace eps

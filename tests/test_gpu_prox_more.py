@@ -1,0 +1,347 @@
+"""GPU parity for the remaining proximal / epigraph operators: every case
+goes through the C ABI (eps_eval_prox) and is compared with the oracle on the same seeded input.
+
+The device algorithms differ from the reference's host ones (thresholds by Newton on the
+piecewise-linear equation instead of std::sort; per-element / scalar Newton instead of a global
+damped Newton), so agreement is to the tolerance both converge to, stated per test: fp64 mode
+1e-8 (the reference stops its Newton iterations at residuals of 1e-10 ... 1e-12), fp32 storage
+5e-4 relative.  SUM_LARGEST's epigraph is a bisection to 1e-5 in the reference itself."""
+
+import numpy as np
+import pytest
+
+from epsilon_amd import ir, wire
+from epsilon_amd.wire import ProxFunction
+from oracle import epsilon_oracle as orc
+from .test_oracle_prox_more import project_sum_largest_epigraph
+
+pytestmark = pytest.mark.gpu
+
+N = 10
+
+
+@pytest.fixture(params=["f64", "f32"])
+def dtype(request, solve_mod):
+    solve_mod.set_option("dtype", request.param)
+    yield request.param
+    solve_mod.set_option("dtype", "f32")
+
+
+def tol_for(dtype, f64=1e-8, f32=5e-4):
+    return dict(rtol=f64, atol=f64) if dtype == "f64" else dict(rtol=f32, atol=f32)
+
+
+def run(solve_mod, expr, lam, v_map, tol):
+    fb = expr.proto.SerializeToString()
+    vb = {k: np.asarray(v, dtype=np.float64).tobytes(order="F") for k, v in v_map.items()}
+    got = solve_mod.eval_prox(fb, lam, expr.data, vb)
+    want = orc.eval_prox(fb, lam, expr.data, vb)
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_allclose(np.frombuffer(got[k]), np.frombuffer(want[k]), err_msg=k, **tol)
+    return {k: np.frombuffer(v) for k, v in got.items()}
+
+
+def both(solve_mod, expr, lam, v_map):
+    fb = expr.proto.SerializeToString()
+    vb = {k: np.asarray(v, dtype=np.float64).tobytes(order="F") for k, v in v_map.items()}
+    got = {k: np.frombuffer(v) for k, v in solve_mod.eval_prox(fb, lam, expr.data, vb).items()}
+    want = {k: np.frombuffer(v) for k, v in orc.eval_prox(fb, lam, expr.data, vb).items()}
+    assert set(got) == set(want)
+    return got, want
+
+
+VECTOR_PROX = {
+    "max": (ProxFunction.MAX, {}),
+    "sum_largest_1": (ProxFunction.SUM_LARGEST, dict(sum_largest_params=wire.SumLargestParams(k=1))),
+    "sum_largest_4": (ProxFunction.SUM_LARGEST, dict(sum_largest_params=wire.SumLargestParams(k=4))),
+    "sum_largest_9": (ProxFunction.SUM_LARGEST, dict(sum_largest_params=wire.SumLargestParams(k=9))),
+    "log_sum_exp": (ProxFunction.LOG_SUM_EXP, {}),
+    "sum_exp": (ProxFunction.SUM_EXP, {}),
+    "sum_logistic": (ProxFunction.SUM_LOGISTIC, {}),
+    "sum_neg_entr": (ProxFunction.SUM_NEG_ENTR, {}),
+    "sum_inv_pos": (ProxFunction.SUM_INV_POS, {}),
+    "sum_neg_log": (ProxFunction.SUM_NEG_LOG, {}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VECTOR_PROX))
+@pytest.mark.parametrize("n", [N, 1, 700])
+def test_vector_prox(solve_mod, dtype, name, n):
+    """prox_test.py:170-194 (MAX, SUM_LARGEST, LOG_SUM_EXP, the smooth sums); n = 700 takes the
+    256-lane group path, n = 1 the single-lane one."""
+    typ, kw = VECTOR_PROX[name]
+    for trial in range(3):
+        rng = np.random.RandomState(trial)
+        x = ir.variable(n, 1, "var:x")
+        v, lam = rng.randn(n), abs(rng.randn()) + 0.05
+        run(solve_mod, ir.prox(typ, x, **kw), lam, {"var:x": v}, tol_for(dtype))
+
+
+@pytest.mark.parametrize("name", ["max", "sum_largest_4", "log_sum_exp", "sum_exp"])
+def test_vector_prox_scaled_argument(solve_mod, dtype, name):
+    """f(a*x + b): VectorProx pre/post scaling (vector_prox.cc:51-70) around the new operators."""
+    typ, kw = VECTOR_PROX[name]
+    rng = np.random.RandomState(7)
+    x = ir.variable(N, 1, "var:x")
+    arg = ir.add(ir.linear_map(ir.scalar(-1.7, N), x), ir.scalar_constant(0.3, (N, 1)))
+    run(solve_mod, ir.prox(typ, arg, alpha=0.6, **kw), 0.8, {"var:x": rng.randn(N)}, tol_for(dtype))
+
+
+def test_sum_largest_prox_defining_equation(solve_mod, dtype):
+    """x = v - u with 0 <= u <= lam and sum(u) = k lam, also for a lam so large that every entry
+    sits inside the window - where the reference's sweep stops early (sum_largest.cc:36-55:
+    sum(u) - k lam = -0.059 on this input) and the device result is the correct one."""
+    rng = np.random.RandomState(3)
+    v = np.abs(rng.randn(N)) + 0.2
+    x = ir.variable(N, 1, "var:x")
+    e = ir.prox(ProxFunction.SUM_LARGEST, x, sum_largest_params=wire.SumLargestParams(k=4))
+    for lam in (0.5, 1.0, 1.5, 2.0, 5.0):
+        got, want = both(solve_mod, e, lam, {"var:x": v})
+        u = v - got["var:x"]
+        tol = 1e-9 if dtype == "f64" else 2e-5
+        assert u.min() >= -tol and u.max() <= lam + tol
+        np.testing.assert_allclose(u.sum(), 4 * lam, atol=10 * tol)
+        if lam <= 1.5:
+            np.testing.assert_allclose(got["var:x"], want["var:x"], **tol_for(dtype))
+
+
+def test_max_prox_ties_and_zero_lambda(solve_mod, dtype):
+    x = ir.variable(6, 1, "var:x")
+    v = np.array([1.0, 3.0, 3.0, -2.0, 3.0, 0.5])
+    got = run(solve_mod, ir.prox(ProxFunction.MAX, x), 0.75, {"var:x": v}, tol_for(dtype))
+    np.testing.assert_allclose(got["var:x"], np.minimum(v, 2.75), atol=1e-6)
+
+
+def test_smooth_prox_elementwise_lambda(solve_mod, dtype):
+    """diagonal scaling -> per-element lambda (vector_prox.cc:72-118), incl. a zero weight."""
+    rng = np.random.RandomState(3)
+    w = rng.rand(N) + 0.5
+    x = ir.variable(N, 1, "var:x")
+    for typ in (ProxFunction.SUM_EXP, ProxFunction.SUM_LOGISTIC, ProxFunction.SUM_NEG_LOG):
+        e = ir.prox(typ, ir.linear_map(ir.diagonal_matrix(w), x))
+        run(solve_mod, e, 0.9, {"var:x": rng.randn(N)}, tol_for(dtype))
+
+
+# Smooth epigraphs: the reference's joint Newton (newton.cc:114-194) builds its step from the
+# Schur complement r_x'(I + lam H)^-1 r_x - the residual where the gradient belongs (:147-155) -
+# so it is not a Newton direction; with the Armijo search it still descends but often stops at
+# its 100-iteration cap with KKT residuals of 1e-4 ... 1e+2 (kkt_norm of the oracle below; the
+# reference's own test accepts 1e-2, prox_test.py:258).  The device result is therefore held
+# to the KKT conditions themselves (<= 1e-9 in fp64) and compared with the oracle to the
+# accuracy the oracle reached, or not at all where it did not converge.
+SMOOTH_F = {"sum_exp": orc.SumExp, "sum_logistic": orc.Logistic, "sum_inv_pos": orc.InvPos,
+            "sum_neg_entr": orc.NegativeEntropy, "log_sum_exp": orc.LogSumExp}
+
+
+def kkt_norm(f, x, t, v, s):
+    lam = t - s
+    r = np.concatenate([x - v + lam * f.gradf(x), [f.eval(x) - t]])
+    return float(np.linalg.norm(r)), lam
+
+
+EPIGRAPHS = {
+    "max": (ProxFunction.MAX, {}),
+    "sum_largest_4": (ProxFunction.SUM_LARGEST, dict(sum_largest_params=wire.SumLargestParams(k=4))),
+    "log_sum_exp": (ProxFunction.LOG_SUM_EXP, {}),
+    "sum_exp": (ProxFunction.SUM_EXP, {}),
+    "sum_logistic": (ProxFunction.SUM_LOGISTIC, {}),
+    "sum_neg_entr": (ProxFunction.SUM_NEG_ENTR, {}),
+    "sum_inv_pos": (ProxFunction.SUM_INV_POS, {}),
+    "sum_neg_log": (ProxFunction.SUM_NEG_LOG, {}),
+}
+
+
+def check_epigraph(dtype, name, got, want, vx, vs, xkey, tkey, i=None):
+    """One projection (slice i of an axis case): parity with the oracle where it converged, KKT
+    residual of the device result where a smooth function is involved."""
+    gx, gt, wx, wt = got[xkey], got[tkey], want[xkey], want[tkey]
+    if name == "sum_largest_4":  # bisection to |g| <= 1e-5 in the reference (newton.cc:252)
+        tol = dict(rtol=5e-5, atol=5e-5) if dtype == "f64" else dict(rtol=1e-3, atol=1e-3)
+        # The reference's sorted sweep (sum_largest.cc:36-55) leaves its loop when every entry has
+        # entered the window, before sum_i clip(v_i - q, 0, lam) = k lam holds; the bisection on
+        # top of it then settles on a wrong multiplier (9e-3 off on one of these inputs, inside
+        # the reference's own 1e-2 test tolerance).  The independent QP decides.
+        qx, qt = project_sum_largest_epigraph(vx, vs, 4)
+        qp_tol = dict(rtol=2e-4, atol=2e-4) if dtype == "f64" else dict(rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(gx, qx, **qp_tol)
+        np.testing.assert_allclose(gt[0], qt, **qp_tol)
+        if np.max(np.abs(wx - qx)) > 1e-4:
+            return "reference inexact"
+    elif name in ("max", "sum_neg_log"):
+        tol = tol_for(dtype, f64=1e-8, f32=1e-3)
+    else:
+        tol = tol_for(dtype, f64=1e-5, f32=1e-3)
+    if name in SMOOTH_F:
+        f = SMOOTH_F[name]()
+        interior = name not in ("sum_neg_entr", "sum_inv_pos") or np.all(gx > 1.5e-6)
+        r_orc, _ = kkt_norm(f, wx, wt[0], vx, vs)
+        if interior and wt[0] > vs:  # active constraint, no clamped entry: KKT must hold
+            r_gpu, lam = kkt_norm(f, gx, gt[0], vx, vs)
+            assert lam > 0
+            assert r_gpu <= (1e-9 if dtype == "f64" else 2e-4) * max(1.0, np.linalg.norm(vx)), \
+                "device KKT residual %g (oracle: %g)" % (r_gpu, r_orc)
+            if r_orc > 1e-4:
+                return "reference did not converge"
+            loose = min(1e-2, max(1e-5, 100 * r_orc))  # the oracle is only this close itself
+            tol = dict(rtol=max(tol["rtol"], loose), atol=max(tol["atol"], loose))
+        elif not interior:
+            # entries clamped at 1e-6 (proj_feasible): the reference's global line search stalls on
+            # them and leaves the other entries short of their roots; its own test tolerance
+            tol = dict(rtol=3e-2, atol=3e-2)  # (python/epopt/prox_test.py:258 accepts 1e-2)
+    np.testing.assert_allclose(gx, wx, err_msg=name, **tol)
+    np.testing.assert_allclose(gt, wt, err_msg=name, **tol)
+    return "compared"
+
+
+@pytest.mark.parametrize("name", sorted(EPIGRAPHS))
+@pytest.mark.parametrize("n", [N, 300])
+def test_vector_epigraph(solve_mod, dtype, name, n):
+    """prox_test.py:222-238: projection of (v, s) onto {f(x) <= t}; infeasible points, points
+    with entries outside the domain, and an already feasible point (s large)."""
+    typ, kw = EPIGRAPHS[name]
+    x, t = ir.variable(n, 1, "var:x"), ir.variable(1, 1, "var:t")
+    e = ir.prox(typ, x, t, epigraph=True, **kw)
+    outcomes = []
+    for trial in range(4):
+        rng = np.random.RandomState(trial)
+        v, s = rng.randn(n), rng.randn() - 0.5
+        if trial >= 2:
+            v = np.abs(v) + 0.2  # inside the domain of the entropy / inverse
+        got, want = both(solve_mod, e, 1.0, {"var:x": v, "var:t": [s]})
+        outcomes.append(check_epigraph(dtype, name, got, want, v, s, "var:x", "var:t"))
+    if name not in ("sum_neg_log",):  # no easy case in the reference (sum_neg_log.cc:42-90)
+        v = 0.1 * np.abs(np.random.RandomState(9).randn(n)) + 0.5
+        got, want = both(solve_mod, e, 1.0, {"var:x": v, "var:t": [1e4]})
+        np.testing.assert_allclose(got["var:x"], want["var:x"], **tol_for(dtype, f64=1e-12, f32=1e-6))
+        np.testing.assert_allclose(got["var:t"], [1e4], rtol=1e-6)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("name", ["max", "log_sum_exp", "sum_exp"])
+def test_epigraph_with_axis(solve_mod, dtype, name, axis):
+    """prox_test.py:224-225: one projection per column (axis 0) / row (axis 1)."""
+    typ, kw = EPIGRAPHS[name]
+    rng = np.random.RandomState(5)
+    m, n = 7, 5
+    X = ir.variable(m, n, "var:X")
+    t = ir.variable(1, n, "var:t") if axis == 0 else ir.variable(m, 1, "var:t")
+    e = ir.prox(typ, X, t, epigraph=True, has_axis=True, axis=axis, **kw)
+    k = n if axis == 0 else m
+    V, s = rng.randn(m, n), rng.randn(k)
+    got, want = both(solve_mod, e, 1.0, {"var:X": V.reshape(-1, order="F"), "var:t": s})
+    GX, WX = (z["var:X"].reshape((m, n), order="F") for z in (got, want))
+    for i in range(k):
+        sl = (slice(None), i) if axis == 0 else (i, slice(None))
+        check_epigraph(dtype, name, {"x": GX[sl], "t": got["var:t"][i:i + 1]},
+                       {"x": WX[sl], "t": want["var:t"][i:i + 1]}, V[sl], s[i], "x", "t")
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("shape", [(4, 6), (2000, 3), (3, 1500)])
+def test_norm2_axis_group_lasso(solve_mod, dtype, axis, shape):
+    """NORM_2 over rows / columns (group lasso); tall and wide shapes take the one-lane-per-row
+    and the group-per-segment paths."""
+    rng = np.random.RandomState(4)
+    m, n = shape
+    X = ir.variable(m, n, "var:X")
+    e = ir.prox(ProxFunction.NORM_2, X, has_axis=True, axis=axis)
+    run(solve_mod, e, 0.9, {"var:X": rng.randn(m * n)}, tol_for(dtype))
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_max_prox_axis(solve_mod, dtype, axis):
+    rng = np.random.RandomState(6)
+    m, n = 9, 1100
+    X = ir.variable(m, n, "var:X")
+    e = ir.prox(ProxFunction.MAX, X, has_axis=True, axis=axis)
+    run(solve_mod, e, 0.7, {"var:X": rng.randn(m * n)}, tol_for(dtype))
+
+
+def test_kl_div(solve_mod, dtype):  # prox_test.py:190,231
+    rng = np.random.RandomState(1)
+    n = 40
+    p, q, t = ir.variable(n, 1, "var:p"), ir.variable(n, 1, "var:q"), ir.variable(1, 1, "var:t")
+    for trial in range(3):
+        u, v = rng.randn(n) + 0.5, rng.randn(n) + 0.5
+        run(solve_mod, ir.prox(ProxFunction.SUM_KL_DIV, p, q), abs(rng.randn()) + 0.1,
+            {"var:p": u, "var:q": v}, tol_for(dtype, f64=1e-9))
+    p1, q1 = ir.variable(1, 1, "var:p"), ir.variable(1, 1, "var:q")
+    for trial in range(3):
+        u, v, s = rng.randn() + 1, rng.randn() + 1, -abs(rng.randn())
+        run(solve_mod, ir.prox(ProxFunction.SUM_KL_DIV, p1, q1, t, epigraph=True), 1.0,
+            {"var:p": [u], "var:q": [v], "var:t": [s]}, tol_for(dtype, f64=1e-8, f32=1e-3))
+
+
+def test_exp_epigraph(solve_mod, dtype):  # prox_test.py:222
+    rng = np.random.RandomState(2)
+    n = 300
+    x, z = ir.variable(n, 1, "var:x"), ir.variable(n, 1, "var:z")
+    run(solve_mod, ir.prox(ProxFunction.EXP, x, z, epigraph=True), 1.0,
+        {"var:x": rng.randn(n), "var:z": rng.randn(n)}, tol_for(dtype, f64=1e-9))
+
+
+def test_second_order_cone(solve_mod, dtype):  # prox_test.py:179-183,276-288
+    x, t = ir.variable(N, 1, "var:x"), ir.variable(1, 1, "var:t")
+    e = ir.prox(ProxFunction.SECOND_ORDER_CONE, t, x, arg_size=[(1, 1), (1, N)])
+    cases = [(np.zeros(N), 0.0), (np.arange(N), 100.0), (np.arange(N), 10.0),
+             (np.arange(N), -100.0), (np.arange(N), -10.0)]
+    for v, s in cases:
+        run(solve_mod, e, 1.0, {"var:x": v.astype(float), "var:t": [s]}, tol_for(dtype, f64=1e-12, f32=1e-5))
+    for trial in range(4):
+        rng = np.random.RandomState(trial)
+        ax, at, bx, bt = rng.randn(), abs(rng.randn()) + 0.1, rng.randn(), rng.randn()
+        targ = ir.add(ir.linear_map(ir.scalar(at, 1), t), ir.scalar_constant(bt, (1, 1)))
+        xarg = ir.add(ir.linear_map(ir.scalar(ax, N), x), ir.scalar_constant(bx, (N, 1)))
+        e2 = ir.prox(ProxFunction.SECOND_ORDER_CONE, targ, xarg, arg_size=[(1, 1), (1, N)])
+        run(solve_mod, e2, 1.0, {"var:x": rng.randn(N), "var:t": [rng.randn()]},
+            tol_for(dtype, f64=1e-11, f32=2e-5))
+    rng = np.random.RandomState(3)
+    for (m, n) in [(5, 4), (3000, 3)]:
+        X, tv = ir.variable(m, n, "var:X"), ir.variable(m, 1, "var:t")
+        e3 = ir.prox(ProxFunction.SECOND_ORDER_CONE, tv, X, arg_size=[(m, 1), (m, n)])
+        run(solve_mod, e3, 1.0, {"var:X": rng.randn(m * n), "var:t": rng.randn(m)},
+            tol_for(dtype, f64=1e-12, f32=1e-5))
+
+
+def sym(rng, n):
+    A = rng.randn(n, n)
+    return (A + A.T) / 2
+
+
+MATRIX = {
+    "semidefinite": ProxFunction.SEMIDEFINITE,
+    "neg_log_det": ProxFunction.NEG_LOG_DET,
+    "lambda_max": ProxFunction.LAMBDA_MAX,
+}
+
+
+@pytest.mark.parametrize("name", sorted(MATRIX))
+@pytest.mark.parametrize("n", [3, 8, 33])
+def test_symmetric_matrix_prox(solve_mod, dtype, name, n):
+    """prox_test.py:169,172,184.  Eigenvalues come from the Jacobi SVD of the shifted matrix; a
+    matrix with a +-lambda eigenvalue pair is included (the case a plain SVD cannot resolve)."""
+    rng = np.random.RandomState(n)
+    X = ir.variable(n, n, "var:X")
+    e = ir.prox(MATRIX[name], X)
+    V = rng.randn(n, n) if name == "semidefinite" else sym(rng, n)
+    tol = tol_for(dtype, f64=1e-8, f32=2e-3)
+    run(solve_mod, e, 0.6, {"var:X": V.reshape(-1, order="F")}, tol)
+    Q, _ = np.linalg.qr(rng.randn(n, n))
+    d = rng.randn(n)
+    d[1] = -d[0]
+    P = (Q * d) @ Q.T
+    run(solve_mod, e, 0.6, {"var:X": ((P + P.T) / 2).reshape(-1, order="F")}, tol)
+
+
+@pytest.mark.parametrize("name", ["lambda_max", "neg_log_det", "norm_nuclear"])
+def test_matrix_epigraphs(solve_mod, dtype, name):  # prox_test.py:221,226,229
+    rng = np.random.RandomState(4)
+    n = 6
+    X, t = ir.variable(n, n, "var:X"), ir.variable(1, 1, "var:t")
+    typ = dict(MATRIX, norm_nuclear=ProxFunction.NORM_NUCLEAR)[name]
+    e = ir.prox(typ, X, t, epigraph=True)
+    for trial in range(3):
+        V = sym(rng, n) if name != "norm_nuclear" else rng.randn(n, n)
+        run(solve_mod, e, 1.0, {"var:X": V.reshape(-1, order="F"), "var:t": [rng.randn()]},
+            tol_for(dtype, f64=1e-7, f32=3e-3))
