@@ -128,6 +128,11 @@ void SegMaxEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, 
 void SegSumLargestProx(const DVec& x, const DVec& v, double lam, int k, const Segs& S);
 void SegSumLargestEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, int k,
                            const Segs& S);
+// scaled-zone epigraph per segment; alpha/beta vectors (if given) are indexed by the position
+// within the segment (scaled_zone.cc:34-44 sizes them with the slice length)
+void SegZoneEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, double alpha,
+                     double beta, const DVec* alpha_vec, const DVec* beta_vec, double M,
+                     const Segs& S);
 // one second-order cone per segment: (x_s, t_s) = proj{||x|| <= beta t} (second_order_cone.cc:58-79)
 void SegSocProject(const DVec& x, const DVec& t, const DVec& v, const DVec& tin, double beta,
                    const Segs& S);

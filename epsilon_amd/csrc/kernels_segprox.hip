@@ -307,6 +307,70 @@ __global__ __launch_bounds__(kBlock) void SegSumLargestEpiKernel(T* x, T* tout, 
   if (c.lane == 0) tout[c.seg] = static_cast<T>(lam + s);
 }
 
+// ---- scaled-zone epigraph per segment (reference prox/scaled_zone.cc:123-279 under the axis loop)
+// keys k_i = (|y_i| - M)/w_i, weights w_i^2; lam is the root of sum w^2 max(k - lam, 0) = s + lam,
+// found by Newton from lam = 0 on the convex piecewise-linear function (Michelot), on chip.
+
+template <class T, int G>
+__global__ __launch_bounds__(kBlock) void SegZoneEpiKernel(T* x, T* tout, const T* v, const T* sin,
+                                                           double alpha_s, double beta_s,
+                                                           const T* alpha_v, const T* beta_v,
+                                                           double M, Segs S) {
+  SegCtx c;
+  if (!SegInit<G>(S, &c)) return;
+  const double s = static_cast<double>(sin[c.seg]);
+  auto weight = [&](int64_t p, double y) {
+    const double a = alpha_v ? static_cast<double>(alpha_v[p]) : alpha_s;
+    const double b = beta_v ? static_cast<double>(beta_v[p]) : beta_s;
+    return y > 0 ? a : b;
+  };
+  double fval = 0;
+  SEG_FOR(p) {
+    const double y = static_cast<double>(SEG_AT(v, p));
+    const double w = weight(p, y);
+    if (fabs(y) > M && w != 0) fval += w * (fabs(y) - M);
+  }
+  fval = GroupSum<G>(fval);
+  double lam = 0;
+  if (!(fval <= s)) {
+    double cprev = -1;
+    for (int it = 0; it < 256; ++it) {
+      double swk = 0, sw2 = 0, cnt = 0;
+      SEG_FOR(p) {
+        const double y = static_cast<double>(SEG_AT(v, p));
+        const double w = weight(p, y);
+        if (fabs(y) > M && w != 0) {
+          const double ex = fabs(y) - M;
+          if (ex / w > lam) {
+            swk += w * ex;
+            sw2 += w * w;
+            cnt += 1;
+          }
+        }
+      }
+      swk = GroupSum<G>(swk);
+      sw2 = GroupSum<G>(sw2);
+      cnt = GroupSum<G>(cnt);
+      if (cnt == cprev) break;
+      cprev = cnt;
+      lam = (swk - s) / (sw2 + 1);
+    }
+  }
+  SEG_FOR(p) {
+    const double y = static_cast<double>(SEG_AT(v, p));
+    const double a = alpha_v ? static_cast<double>(alpha_v[p]) : alpha_s;
+    const double b = beta_v ? static_cast<double>(beta_v[p]) : beta_s;
+    double out;  // ApplyScaledZone (scaled_zone.cc:78-104), same branch order
+    if (fabs(y) <= M) out = y;
+    else if (y > M + lam * a) out = y - lam * a;
+    else if (y < -M - lam * b) out = y + lam * b;
+    else if (y > 0) out = M;
+    else out = -M;
+    SEG_AT(x, p) = static_cast<T>(out);
+  }
+  if (c.lane == 0) tout[c.seg] = static_cast<T>(s + lam);
+}
+
 // ---- second-order cone, one cone per segment (reference prox/second_order_cone.cc:58-79) -----------
 
 template <class T, int G>
@@ -798,6 +862,22 @@ void SegSumLargestEpigraph(const DVec& x, const DVec& t, const DVec& v, const DV
   ProfScope prof("seg_sum_largest_epi", S.count, S.len);
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegSumLargestEpiKernel, x.as<T>(), t.as<T>(), v.as<T>(),
                                       s.as<T>(), static_cast<double>(k), S));
+}
+
+void SegZoneEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, double alpha,
+                     double beta, const DVec* alpha_vec, const DVec* beta_vec, double M,
+                     const Segs& S) {
+  EPS_CHECK(x.n == v.n && x.dt == v.dt && t.n == S.count && s.n == S.count && t.dt == v.dt &&
+            s.dt == v.dt);
+  if (alpha_vec) EPS_CHECK(alpha_vec->n == S.len && alpha_vec->dt == v.dt);
+  if (beta_vec) EPS_CHECK(beta_vec->n == S.len && beta_vec->dt == v.dt);
+  CheckSegs(S, v.n);
+  if (S.count == 0) return;
+  ProfScope prof("seg_zone_epi", S.count, S.len);
+  EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegZoneEpiKernel, x.as<T>(), t.as<T>(), v.as<T>(),
+                                      s.as<T>(), alpha, beta,
+                                      alpha_vec ? alpha_vec->as<T>() : nullptr,
+                                      beta_vec ? beta_vec->as<T>() : nullptr, M, S));
 }
 
 void SegSocProject(const DVec& x, const DVec& t, const DVec& v, const DVec& tin, double beta,

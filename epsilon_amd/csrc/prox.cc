@@ -324,7 +324,6 @@ class ScaledZoneEpigraph final : public VectorProx {
  public:
   void Init(const ProxOperatorArg& arg) override {
     VectorProx::Init(arg);
-    EPS_CHECK_MSG(!arg.prox_function().has_axis, "epigraph with an axis is not supported yet");
     InitZoneParams(arg, &alpha_, &beta_, &M_, &n_);
   }
 
@@ -332,6 +331,15 @@ class ScaledZoneEpigraph final : public VectorProx {
   void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
     const DVec& v = input.value_vec(0);
     const DVec& sv = input.value_vec(1);
+    if (input.prox_function().has_axis) {  // one projection per row / column, solved on chip
+      DVec x = DVec::Empty(v.n, v.dt), t = DVec::Empty(sv.n, sv.dt);
+      k::SegZoneEpigraph(x, t, v, sv, alpha_.value, beta_.value,
+                         alpha_.is_vec ? &alpha_.vec : nullptr, beta_.is_vec ? &beta_.vec : nullptr,
+                         M_, SegsOf(input.prox_function(), 0, v.n));
+      output->set_value(0, x);
+      output->set_value(1, t);
+      return;
+    }
     EPS_CHECK(sv.n == 1);
     Runtime& rt = Runtime::Get();
     const double s = sv.ToHost()[0];

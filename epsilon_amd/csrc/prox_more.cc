@@ -320,7 +320,10 @@ class OrthoInvariantProx : public VectorProx {
       const int slot = rt.NewSlot();
       k::SumSq(W, rt.SlotPtr(slot), false);
       rt.FetchSlots();
-      shift = std::sqrt(rt.SlotValue(slot)) * 1.0625 + 1e-300;
+      // c > ||S||_2 makes S + cI positive definite; a (numerically) zero S is shifted by 1 so
+      // that the Jacobi sweep has well-scaled columns to work on
+      const double fro = std::sqrt(rt.SlotValue(slot));
+      shift = fro > 1e-150 ? fro * 1.0625 : 1.0;
       k::AddDiag(W, n_, n_, shift, nullptr);
     } else {
       W = y.Clone();

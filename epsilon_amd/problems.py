@@ -176,3 +176,88 @@ def multiclass_hinge(X, Y, lam, c_vec=None):
 def multiclass_hinge_objective(X, Y, lam, Theta):
     S = X.dot(Theta) + 1 - Y
     return float(S.max(axis=1).sum() - np.sum(X.T.dot(Y) * Theta) + lam * np.sum(Theta ** 2))
+
+
+def group_lasso(m, n, k, lam=None, seed=0):
+    """sum_square(A X' - B) + lam * sum_i ||X_i||_2 over the rows X_i  s.t.  X' - X = 0
+    (reference python/epopt/problems/group_lasso.py: the NORM_2 prox carries axis = 1)."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    X0 = rng.randn(n, k) * (rng.rand(n, 1) < 0.2)
+    B = A.dot(X0) + 0.1 * rng.randn(m, k)
+    if lam is None:
+        lam = 0.3 * np.sqrt((A.T.dot(B) ** 2).sum(axis=1)).max()
+    Xp = ir.variable(n, k, "separate:var:X:sum_square")
+    X = ir.variable(n, k, "var:X")
+    f0 = ir.prox(ProxFunction.SUM_SQUARE,
+                 ir.add(ir.linear_map(ir.left_matrix_product(ir.dense_matrix(A), k),
+                                      ir.reshape(Xp, n * k, 1)),
+                        ir.linear_map(ir.scalar(-1, m * k), ir.constant(B.reshape(-1, 1, order="F")))),
+                 alpha=1.0, arg_size=[(m * k, 1)])
+    f1 = ir.prox(ProxFunction.NORM_2, X, alpha=lam, has_axis=True, axis=1)
+    c = ir.zero(ir.add(ir.reshape(Xp, n * k, 1),
+                       ir.linear_map(ir.scalar(-1, n * k), ir.reshape(X, n * k, 1))))
+    return ir.Problem([f0, f1], [c]), dict(A=A, B=B, lam=lam)
+
+
+def group_lasso_objective(A, B, lam, X):
+    return float(np.sum((A.dot(X) - B) ** 2) + lam * np.sqrt((X ** 2).sum(axis=1)).sum())
+
+
+def logreg_l1(m, n, lam=None, seed=0):
+    """sum_i logistic(-y_i a_i^T x) + lam ||x||_1 in graph form
+    (reference python/epopt/problems/logreg_l1.py, compiled like docs/notebooks):
+
+      sum_logistic(z) + norm_1(x)[lam] + zero(C x' - z')   s.t.  x' - x = 0,  z' - z = 0
+    with C = -diag(y) A."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    x0 = rng.randn(n) * (rng.rand(n) < 0.3)
+    y = np.sign(A.dot(x0) + 0.1 * rng.randn(m))
+    C = -y[:, None] * A
+    if lam is None:
+        lam = 0.1 * np.abs(C.T.dot(np.full(m, 0.5))).max()
+    z = ir.variable(m, 1, "var:z")
+    zp = ir.variable(m, 1, "separate:var:z:zero")
+    x = ir.variable(n, 1, "var:x")
+    xp = ir.variable(n, 1, "separate:var:x:zero")
+    f0 = ir.prox(ProxFunction.SUM_LOGISTIC, z, alpha=1.0)
+    f1 = ir.prox(ProxFunction.NORM_1, x, alpha=lam)
+    f2 = ir.prox(ProxFunction.ZERO,
+                 ir.add(ir.linear_map(ir.dense_matrix(C), xp), ir.linear_map(ir.scalar(-1, m), zp)))
+    c0 = ir.zero(ir.add(xp, ir.linear_map(ir.scalar(-1, n), x)))
+    c1 = ir.zero(ir.add(zp, ir.linear_map(ir.scalar(-1, m), z)))
+    return ir.Problem([f0, f1, f2], [c0, c1]), dict(C=C, lam=lam)
+
+
+def logreg_l1_objective(C, lam, x):
+    return float(np.sum(np.logaddexp(0, C.dot(x))) + lam * np.abs(x).sum())
+
+
+def covsel(n, m=None, lam=0.1, seed=0):
+    """Sparse inverse covariance selection, -log_det(X) + <S, X'> + lam ||X''||_1
+    (reference python/epopt/problems/covsel.py) in consensus form:
+
+      neg_log_det(X) + affine(<S, X1>) + norm_1(X2)[lam]   s.t.  X1 - X = 0,  X2 - X = 0"""
+    rng = np.random.RandomState(seed)
+    m = m or 10 * n
+    P = np.eye(n) + 0.3 * sp.rand(n, n, 0.2, random_state=rng).toarray()
+    P = (P + P.T) / 2 + n * 0.05 * np.eye(n)
+    Z = rng.multivariate_normal(np.zeros(n), np.linalg.inv(P), size=m)
+    S = Z.T.dot(Z) / m
+    X = ir.variable(n, n, "var:X")
+    X1 = ir.variable(n * n, 1, "separate:var:X:affine")
+    X2 = ir.variable(n * n, 1, "separate:var:X:norm_1")
+    f0 = ir.prox(ProxFunction.NEG_LOG_DET, X, alpha=1.0)
+    f1 = ir.prox(ProxFunction.AFFINE,
+                 ir.linear_map(ir.dense_matrix(S.reshape(1, -1, order="F")), X1), alpha=1.0)
+    f2 = ir.prox(ProxFunction.NORM_1, X2, alpha=lam)
+    Xv = ir.reshape(X, n * n, 1)
+    c0 = ir.zero(ir.add(X1, ir.linear_map(ir.scalar(-1, n * n), Xv)))
+    c1 = ir.zero(ir.add(X2, ir.linear_map(ir.scalar(-1, n * n), Xv)))
+    return ir.Problem([f0, f1, f2], [c0, c1]), dict(S=S, lam=lam)
+
+
+def covsel_objective(S, lam, X):
+    sign, logdet = np.linalg.slogdet(X)
+    return float(-logdet + np.sum(S * X) + lam * np.abs(X).sum()) if sign > 0 else float("inf")

@@ -398,6 +398,22 @@ def test_multiclass_hinge_problem(solve_mod, dtype):
         np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
 
 
+@pytest.mark.parametrize("name", ["group_lasso", "logreg_l1", "covsel"])
+def test_more_benchmark_problems(solve_mod, dtype, name):
+    """Drivers over the batched NORM_2 (group lasso), SUM_LOGISTIC + ZERO graph form (l1 logistic
+    regression) and NEG_LOG_DET (sparse inverse covariance) operators: same stopping iteration
+    and iterates as the oracle."""
+    prob, info = {"group_lasso": lambda: problems.group_lasso(30, 20, 3),
+                  "logreg_l1": lambda: problems.logreg_l1(40, 15),
+                  "covsel": lambda: problems.covsel(6)}[name]()
+    params = wire.SolverParams(max_iterations=60)
+    sg, xg, so, xo = solve_both(solve_mod, prob, params)
+    assert sg.num_iterations == so.num_iterations and sg.state == so.state
+    tol = dict(rtol=1e-6, atol=1e-8) if dtype == "f64" else dict(rtol=5e-3, atol=5e-3)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
+
+
 def test_error_reporting(solve_mod):
     """A failed CHECK surfaces as _solve.error with a message (reference: longjmp ->
     _solve.error("CHECK failed"), solvemodule.cc:245-248)."""

@@ -238,6 +238,22 @@ def test_epigraph_with_axis(solve_mod, dtype, name, axis):
 
 
 @pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("kind", ["hinge", "norm_1", "deadzone"])
+def test_scaled_zone_epigraph_with_axis(solve_mod, dtype, kind, axis):
+    """prox_test.py:235-236 (f_hinge_axis0/1 <= t_rvec / t_vec)."""
+    rng = np.random.RandomState(8)
+    m, n = 6, 9
+    X = ir.variable(m, n, "var:X")
+    t = ir.variable(1, n, "var:t") if axis == 0 else ir.variable(m, 1, "var:t")
+    typ, kw = {"hinge": (ProxFunction.SUM_HINGE, {}), "norm_1": (ProxFunction.NORM_1, {}),
+               "deadzone": (ProxFunction.SUM_DEADZONE,
+                            dict(scaled_zone_params=wire.ProxScaledZoneParams(m=0.3)))}[kind]
+    e = ir.prox(typ, X, t, epigraph=True, has_axis=True, axis=axis, **kw)
+    k = n if axis == 0 else m
+    run(solve_mod, e, 1.0, {"var:X": rng.randn(m * n), "var:t": 0.5 * rng.randn(k)}, tol_for(dtype))
+
+
+@pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("shape", [(4, 6), (2000, 3), (3, 1500)])
 def test_norm2_axis_group_lasso(solve_mod, dtype, axis, shape):
     """NORM_2 over rows / columns (group lasso); tall and wide shapes take the one-lane-per-row
@@ -332,6 +348,8 @@ def test_symmetric_matrix_prox(solve_mod, dtype, name, n):
     d[1] = -d[0]
     P = (Q * d) @ Q.T
     run(solve_mod, e, 0.6, {"var:X": ((P + P.T) / 2).reshape(-1, order="F")}, tol)
+    run(solve_mod, e, 0.6, {"var:X": np.zeros(n * n)}, tol)  # the first ADMM iterate
+    run(solve_mod, e, 0.6, {"var:X": 1e-9 * V.reshape(-1, order="F")}, tol)
 
 
 @pytest.mark.parametrize("name", ["lambda_max", "neg_log_det", "norm_nuclear"])

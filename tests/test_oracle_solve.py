@@ -104,3 +104,45 @@ def test_multiclass_hinge_problem():
     f = lambda t: problems.multiclass_hinge_objective(X, Y, 0.1, t.reshape(8, 3))
     best = min(optimize.minimize(f, Th.ravel(), method="Powell", options=dict(maxiter=20000)).fun, obj)
     assert obj <= best * (1 + 2e-2) + 1e-3
+
+
+def test_group_lasso_problem():  # NORM_2 with an axis inside the driver
+    prob, info = problems.group_lasso(30, 20, 3)
+    S, x = solve(prob, max_iterations=500)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    X = x["var:X"].reshape((20, 3), order="F")
+    obj = problems.group_lasso_objective(info["A"], info["B"], info["lam"], X)
+    # independent proximal-gradient solve
+    A, B, lam = info["A"], info["B"], info["lam"]
+    L = 2 * np.linalg.norm(A, 2) ** 2
+    Z = np.zeros((20, 3))
+    for _ in range(5000):
+        G = Z - 2 * A.T @ (A @ Z - B) / L
+        nr = np.sqrt((G ** 2).sum(axis=1, keepdims=True))
+        Z = np.maximum(1 - lam / L / np.maximum(nr, 1e-300), 0) * G
+    opt = problems.group_lasso_objective(A, B, lam, Z)
+    assert obj <= opt * (1 + 1e-2) + 1e-4
+
+
+def test_logreg_l1_problem():  # SUM_LOGISTIC + ZERO graph form
+    prob, info = problems.logreg_l1(40, 15)
+    S, x = solve(prob, max_iterations=500)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    obj = problems.logreg_l1_objective(info["C"], info["lam"], x["var:x"])
+    r = optimize.minimize(lambda w: problems.logreg_l1_objective(info["C"], info["lam"], w),
+                          np.zeros(15), method="Powell", options=dict(xtol=1e-8, ftol=1e-12, maxiter=100000))
+    assert obj <= r.fun * (1 + 1e-2) + 1e-4
+
+
+def test_covsel_problem():  # NEG_LOG_DET on the symmetric part
+    prob, info = problems.covsel(6)
+    S, x = solve(prob, max_iterations=500)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    X = x["var:X"].reshape((6, 6), order="F")
+    X = (X + X.T) / 2
+    assert np.all(np.linalg.eigvalsh(X) > 0)
+    obj = problems.covsel_objective(info["S"], info["lam"], X)
+    # first-order optimality of -logdet X + <S, X> + lam |X|_1:  S - X^-1 in lam * d|X|
+    G = info["S"] - np.linalg.inv(X)
+    assert np.all(np.abs(G) <= info["lam"] + 5e-2)
+    assert obj < problems.covsel_objective(info["S"], info["lam"], np.eye(6))
