@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -23,71 +24,88 @@ namespace k {
 namespace {
 
 constexpr int NB = 64;
-constexpr int kBlock = 256;
+
+// Broadcast of lane `L`'s value (L is a compile-time constant after unrolling): v_readlane_b32,
+// one scalar-unit instruction, no LDS.
+template <int L> __device__ inline float ReadLane(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), L));
+}
+template <int L> __device__ inline double ReadLane(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(b), L);
+  const int hi = __builtin_amdgcn_readlane(static_cast<int>(b >> 32), L);
+  return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) |
+                                        static_cast<unsigned int>(lo));
+}
+
+// Compile-time loops so that every register index and every lane index is a constant.
+template <int I, int N> struct StaticFor {
+  template <class F> __device__ static inline void Run(F&& f) {
+    f(std::integral_constant<int, I>());
+    StaticFor<I + 1, N>::Run(f);
+  }
+};
+template <int N> struct StaticFor<N, N> {
+  template <class F> __device__ static inline void Run(F&&) {}
+};
 
 // Factor the kb x kb block at W (ld) in place (lower Cholesky) and write inv(L) (dense NB x NB,
-// zeros above the diagonal, ld = NB) to Dinv.  One workgroup.  *flag != 0 on a bad pivot.
+// zeros above the diagonal, ld = NB) to Dinv.  ONE WAVE, register resident: lane i owns row i
+// of the block (64 registers); the pivot column is broadcast lane by lane with v_readlane, so
+// the 64 elimination steps need no LDS and no barriers (the previous LDS version spent ~190 us
+// per block in ~400 barriers; this one ~4000 readlane + FMA pairs).  *flag != 0 on a bad pivot.
 template <class T>
-__global__ __launch_bounds__(kBlock) void PotrfDiagKernel(T* W, int64_t ld, int kb, T* Dinv,
-                                                          int* flag) {
-  __shared__ T S[NB][NB + 1];
-  __shared__ T col[NB];
-  const int t = threadIdx.x;
-  for (int idx = t; idx < NB * NB; idx += kBlock) {
-    const int r = idx % NB, c = idx / NB;
-    T v = T(0);
-    if (r < kb && c < kb) v = (r >= c) ? W[r + c * ld] : T(0);
-    S[r][c] = v;
-  }
-  __syncthreads();
-  for (int j = 0; j < kb; ++j) {
-    if (t == 0) {
-      T d = S[j][j];
-      if (!(d > T(0))) {
-        *flag = 1;
-        d = T(1);
-      }
-      S[j][j] = sqrt(d);
+__global__ __launch_bounds__(64) void PotrfDiagKernel(T* W, int64_t ld, int kb, T* Dinv,
+                                                      int* flag) {
+  const int lane = threadIdx.x;
+  T r[NB];  // row `lane` of the block; identity padding beyond kb
+  StaticFor<0, NB>::Run([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    T v = (lane == c) ? T(1) : T(0);
+    if (lane < kb && c < kb && lane >= c) v = W[lane + static_cast<int64_t>(c) * ld];
+    r[c] = v;
+  });
+  bool bad = false;
+  // right-looking Cholesky: after step j, r[j] holds L[lane][j]
+  StaticFor<0, NB>::Run([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    T d = ReadLane<j>(r[j]);
+    if (!(d > T(0))) {
+      bad = true;
+      d = T(1);
     }
-    __syncthreads();
-    const T djj = S[j][j];
-    for (int i = j + 1 + t; i < kb; i += kBlock) S[i][j] /= djj;
-    __syncthreads();
-    const int w = kb - j - 1;
-    for (int idx = t; idx < w * w; idx += kBlock) {
-      const int r = j + 1 + idx % w, c = j + 1 + idx / w;
-      if (r >= c) S[r][c] -= S[r][j] * S[c][j];
-    }
-    __syncthreads();
-  }
-  // the factor goes back to W before S is overwritten by its inverse
-  for (int idx = t; idx < NB * NB; idx += kBlock) {
-    const int r = idx % NB, c = idx / NB;
-    if (r < kb && c < kb && r >= c) W[r + c * ld] = S[r][c];
-  }
-  __syncthreads();
-  // in-place inverse of the lower-triangular factor, last column first (trti2 order):
+    const T dj = sqrt(d);
+    const T l = lane > j ? r[j] / dj : (lane == j ? dj : T(0));
+    r[j] = l;
+    StaticFor<j + 1, NB>::Run([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      r[c] -= l * ReadLane<c>(l);  // only lanes >= c hold live entries of column c
+    });
+  });
+  if (bad && lane == 0) *flag = 1;
+  StaticFor<0, NB>::Run([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (lane < kb && c < kb && lane >= c) W[lane + static_cast<int64_t>(c) * ld] = r[c];
+  });
+  // X = inv(L), columns last to first (trti2 order):
   //   X[j][j] = 1/L[j][j] ;  X[j+1:, j] = -X[j+1:, j+1:] * L[j+1:, j] * X[j][j]
-  for (int j = kb - 1; j >= 0; --j) {
-    if (t < NB) col[t] = (t > j && t < kb) ? S[t][j] : T(0);
-    __syncthreads();
-    const T ajj = T(1) / S[j][j];
-    T nv = T(0);
-    const bool mine = (t > j && t < kb);
-    if (mine) {
-      T acc = T(0);
-      for (int kk = j + 1; kk <= t; ++kk) acc += S[t][kk] * col[kk];
-      nv = -acc * ajj;
-    }
-    __syncthreads();
-    if (mine) S[t][j] = nv;
-    if (t == j) S[j][j] = ajj;
-    __syncthreads();
-  }
-  for (int idx = t; idx < NB * NB; idx += kBlock) {
-    const int r = idx % NB, c = idx / NB;
-    Dinv[r + c * NB] = (r < kb && c < kb && r >= c) ? S[r][c] : T(0);
-  }
+  // lane t accumulates row t of the product; L[kk][j] is lane kk's r[j].
+  T x[NB];
+  StaticFor<0, NB>::Run([&](auto ii) {
+    constexpr int j = NB - 1 - decltype(ii)::value;
+    const T ajj = T(1) / ReadLane<j>(r[j]);
+    T acc = T(0);
+    StaticFor<j + 1, NB>::Run([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      // x[kk] of lanes < kk is zero (strictly upper part), so no predicate is needed
+      acc += x[kk] * ReadLane<kk>(r[j]);
+    });
+    x[j] = lane > j ? -acc * ajj : (lane == j ? ajj : T(0));
+  });
+  StaticFor<0, NB>::Run([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    Dinv[lane + c * NB] = (lane < kb && c < kb && lane >= c) ? x[c] : T(0);
+  });
 }
 
 DVec Sub(const DVec& W, int64_t i, int64_t j, int64_t ld) {
@@ -114,28 +132,45 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
   DVec panel = DVec::Empty(std::max<int64_t>(n, 1) * NB, dt);
 
   // ---- 1. blocked Cholesky ------------------------------------------------------------------
-  for (int64_t kblk = 0; kblk < nb; ++kblk) {
-    const int64_t k0 = kblk * NB;
-    const int kb = static_cast<int>(std::min<int64_t>(NB, n - k0));
-    DVec Wkk = Sub(W, k0, k0, ld);
-    DVec Dk = dinv.Slice(kblk * NB * NB, NB * NB);
-    if (dt == F32) {
-      hipLaunchKernelGGL(PotrfDiagKernel<float>, dim3(1), dim3(kBlock), 0, s, Wkk.as<float>(), ld,
-                         kb, Dk.as<float>(), flag);
-    } else {
-      hipLaunchKernelGGL(PotrfDiagKernel<double>, dim3(1), dim3(kBlock), 0, s, Wkk.as<double>(),
-                         ld, kb, Dk.as<double>(), flag);
+  // Two-level blocking: 64-wide steps update only the rest of their 256-wide outer panel; the
+  // trailing matrix sees one rank-256 update per outer panel (a rank-64 update of the whole
+  // trailing matrix is HBM-bound: it re-reads and re-writes up to n^2 entries for 64 columns).
+  const int64_t OB = 4 * NB;
+  for (int64_t K0 = 0; K0 < n; K0 += OB) {
+    const int64_t KB = std::min<int64_t>(OB, n - K0);
+    for (int64_t k0 = K0; k0 < K0 + KB; k0 += NB) {
+      const int64_t kblk = k0 / NB;
+      const int kb = static_cast<int>(std::min<int64_t>(NB, n - k0));
+      DVec Wkk = Sub(W, k0, k0, ld);
+      DVec Dk = dinv.Slice(kblk * NB * NB, NB * NB);
+      if (dt == F32) {
+        hipLaunchKernelGGL(PotrfDiagKernel<float>, dim3(1), dim3(64), 0, s, Wkk.as<float>(), ld,
+                           kb, Dk.as<float>(), flag);
+      } else {
+        hipLaunchKernelGGL(PotrfDiagKernel<double>, dim3(1), dim3(64), 0, s, Wkk.as<double>(),
+                           ld, kb, Dk.as<double>(), flag);
+      }
+      const int64_t rem = n - (k0 + kb);
+      if (rem <= 0) continue;
+      DVec W21 = Sub(W, k0 + kb, k0, ld);
+      DVec tmp = panel.Slice(0, rem * kb);
+      MatCopy(false, rem, kb, 1.0, W21, ld, tmp);
+      // L21 = W21 * inv(L11)^T
+      Gemm(false, true, rem, kb, kb, 1.0, tmp, rem, Dk, NB, 0.0, W21, ld);
+      // the remaining columns of this outer panel: W[k0+kb:, k0+kb : K0+KB] -= L21 L21[0:pc]^T
+      const int64_t pc = K0 + KB - (k0 + kb);
+      if (pc > 0) {
+        DVec Wp = Sub(W, k0 + kb, k0 + kb, ld);
+        Gemm(false, true, rem, pc, kb, -1.0, W21, ld, W21, ld, 1.0, Wp, ld);
+      }
     }
-    const int64_t rem = n - (k0 + kb);
-    if (rem <= 0) continue;
-    DVec W21 = Sub(W, k0 + kb, k0, ld);
-    DVec tmp = panel.Slice(0, rem * kb);
-    MatCopy(false, rem, kb, 1.0, W21, ld, tmp);
-    // L21 = W21 * inv(L11)^T
-    Gemm(false, true, rem, kb, kb, 1.0, tmp, rem, Dk, NB, 0.0, W21, ld);
-    // W22 -= L21 L21^T  (lower tiles only)
-    DVec W22 = Sub(W, k0 + kb, k0 + kb, ld);
-    Gemm(false, true, rem, rem, kb, -1.0, W21, ld, W21, ld, 1.0, W22, ld, true);
+    // trailing matrix: W22 -= L21 L21^T with the whole outer panel (lower tiles only)
+    const int64_t rem2 = n - (K0 + KB);
+    if (rem2 > 0) {
+      DVec L21 = Sub(W, K0 + KB, K0, ld);
+      DVec W22 = Sub(W, K0 + KB, K0 + KB, ld);
+      Gemm(false, true, rem2, rem2, KB, -1.0, L21, ld, L21, ld, 1.0, W22, ld, true);
+    }
   }
 
   // ---- 2. X = inv(L) by recursive doubling ---------------------------------------------------
@@ -159,13 +194,38 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
       DVec X21 = Sub(X, r0 + s1, r0, ld);
       EPS_CHECK(tmp2.n >= s2 * s1);
       DVec T = tmp2.Slice(0, s2 * s1);
-      Gemm(false, false, s2, s1, s1, 1.0, L21, ld, X11, ld, 0.0, T, s2);
-      Gemm(false, false, s2, s1, s2, -1.0, X22, ld, T, s2, 0.0, X21, ld);
+      // X11 and X22 are lower triangular: column block j of X11 is zero above row j*cb and row
+      // block i of X22 is zero right of column (i+1)*rb, so the products only run over the
+      // non-zero part of K (62 % of the dense flops with four blocks).
+      const int64_t nsplit = sz >= 1024 ? 4 : 1;
+      const int64_t cb = (s1 + nsplit - 1) / nsplit;
+      for (int64_t c0 = 0; c0 < s1; c0 += cb) {
+        const int64_t cw = std::min<int64_t>(cb, s1 - c0);
+        Gemm(false, false, s2, cw, s1 - c0, 1.0, Sub(L21, 0, c0, ld), ld, Sub(X11, c0, c0, ld), ld,
+             0.0, T.Slice(c0 * s2, cw * s2), s2);
+      }
+      const int64_t rb = (s2 + nsplit - 1) / nsplit;
+      for (int64_t r1 = 0; r1 < s2; r1 += rb) {
+        const int64_t rw = std::min<int64_t>(rb, s2 - r1);
+        Gemm(false, false, rw, s1, r1 + rw, -1.0, Sub(X22, r1, 0, ld), ld, T, s2, 0.0,
+             Sub(X21, r1, 0, ld), ld);
+      }
     }
   }
 
   // ---- 3. W^-1 = X^T X ------------------------------------------------------------------------
-  Gemm(true, false, n, n, n, 1.0, X, ld, X, ld, 0.0, W, ld, true);
+  // Row block p of the lower-triangular X is zero right of column (p+1)*B, so it only touches
+  // the leading (p+1)B x (p+1)B corner of X^T X: a third of the flops of the dense product.
+  {
+    const int64_t B = 1024;
+    Fill(W.Slice(0, n * n), 0.0);
+    for (int64_t p0 = 0; p0 < n; p0 += B) {
+      const int64_t pb = std::min<int64_t>(B, n - p0);
+      const int64_t cp = p0 + pb;  // columns with non-zeros in these rows
+      DVec Xp = Sub(X, p0, 0, ld);
+      Gemm(true, false, cp, cp, pb, 1.0, Xp, ld, Xp, ld, 1.0, W, ld, true);
+    }
+  }
   SymmetrizeFromLower(W, n, ld);
 
   int host_flag = 0;

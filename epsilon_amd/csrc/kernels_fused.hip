@@ -22,6 +22,8 @@
 // vectors are summed by ReducePartials.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace eps {
@@ -191,6 +193,8 @@ bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda) {
 int LassoFusedGrid(int64_t n) {
   int64_t npairs = (n + 1) / 2;
   int64_t g = 512;  // 2 workgroups per CU
+  static const char* env = std::getenv("EPSILON_HIP_FUSED_GRID");  // tuning knob
+  if (env && std::atoi(env) > 0) g = std::atoi(env);
   if (g > npairs) g = npairs;
   return static_cast<int>(g < 1 ? 1 : g);
 }

@@ -15,6 +15,8 @@
 // `lower_only` skips tiles strictly above the diagonal (SYRK-style, half the flops).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -215,9 +217,10 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32Kernel(
 // ------------------------------------------------------------------------------------------
 template <bool CR> struct StageCfg { static constexpr int LD = CR ? 132 : 129; };
 
-template <bool CR>
+template <bool CR, bool INTERIOR>
 __device__ inline void LoadSlab(float4 (&r)[4], const float* __restrict__ X, int64_t ld,
-                                int64_t r0, int64_t k0, int64_t R, int64_t K, bool interior) {
+                                int64_t r0, int64_t k0, int64_t R, int64_t K) {
+  constexpr bool interior = INTERIOR;
   const int t = threadIdx.x;
   if (CR) {
     const int rr4 = (t & 31) * 4;
@@ -292,8 +295,9 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
     const float* __restrict__ B, int64_t ldb, float beta, float* C, int64_t ldc,
     int lower_only) {
   constexpr int LDA = StageCfg<CA>::LD, LDB = StageCfg<CB>::LD;
-  __shared__ __attribute__((aligned(16))) float As[MK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[MK * LDB];
+  // two LDS stages: slab k+1 is written while slab k is still being read, one barrier per slab
+  __shared__ __attribute__((aligned(16))) float As[2][MK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][MK * LDB];
   const int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
   const int64_t j0 = static_cast<int64_t>(blockIdx.y) * MT;
   if (lower_only && i0 + MT <= j0) return;
@@ -313,36 +317,70 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
 
   float4 ra[4], rb[4];
   const int64_t nk = (K + MK - 1) / MK;
-  {
-    const bool in_k = MK <= K;
-    LoadSlab<CA>(ra, A, lda, i0, 0, M, K, in_i && in_k);
-    LoadSlab<CB>(rb, B, ldb, j0, 0, N, K, in_j && in_k);
-  }
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    StoreSlab<CA>(As, ra);
-    StoreSlab<CB>(Bs, rb);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      const int64_t k1 = (kt + 1) * MK;
-      const bool in_k = k1 + MK <= K;
-      LoadSlab<CA>(ra, A, lda, i0, k1, M, K, in_i && in_k);
-      LoadSlab<CB>(rb, B, ldb, j0, k1, N, K, in_j && in_k);
+  const int64_t nfull = (in_i && in_j) ? K / MK : 0;  // slabs that need no bounds checks
+  auto load = [&](int64_t kt) {
+    if (kt < nfull) {
+      LoadSlab<CA, true>(ra, A, lda, i0, kt * MK, M, K);
+      LoadSlab<CB, true>(rb, B, ldb, j0, kt * MK, N, K);
+    } else if (kt < nk) {
+      LoadSlab<CA, false>(ra, A, lda, i0, kt * MK, M, K);
+      LoadSlab<CB, false>(rb, B, ldb, j0, kt * MK, N, K);
     }
-#pragma unroll 4
+  };
+  // One k-slab: MFMAs on stage kt&1 (LDS operands read one k-step ahead), then the prefetched
+  // registers of slab kt+1 go to the other stage, barrier, and the global loads of slab kt+2
+  // are issued - a whole slab of MFMAs ahead of their use.  FAST: slab kt+2 lies fully inside
+  // the operands, so its loads carry no bounds checks (the checked form compiles to a chain of
+  // conditional loads with vmcnt(0) waits).
+  auto slab = [&](auto fast_tag, int64_t kt) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const float* as = As[kt & 1];
+    const float* bs = Bs[kt & 1];
+    float av[2][2], bv[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) av[0][a] = as[lh * LDA + wi * 64 + a * 32 + l31];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bv[0][b] = bs[lh * LDB + wj * 64 + b * 32 + l31];
+#pragma unroll
     for (int kk = 0; kk < MK; kk += 2) {
-      float av[2], bv[2];
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < MK) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = As[(kk + lh) * LDA + wi * 64 + a * 32 + l31];
+        for (int a = 0; a < 2; ++a)
+          av[nxt][a] = as[(kk + 2 + lh) * LDA + wi * 64 + a * 32 + l31];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bv[b] = Bs[(kk + lh) * LDB + wj * 64 + b * 32 + l31];
+        for (int b = 0; b < 2; ++b)
+          bv[nxt][b] = bs[(kk + 2 + lh) * LDB + wj * 64 + b * 32 + l31];
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[b], av[a], acc[a][b], 0, 0, 0);
+          acc[a][b] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(bv[cur][b], av[cur][a], acc[a][b], 0, 0, 0);
+      if (FAST) __builtin_amdgcn_sched_barrier(0);  // keep the read-ahead order
+    }
+    if (FAST || kt + 1 < nk) {
+      StoreSlab<CA>(As[(kt + 1) & 1], ra);
+      StoreSlab<CB>(Bs[(kt + 1) & 1], rb);
     }
     __syncthreads();
-  }
+    if (FAST) {
+      LoadSlab<CA, true>(ra, A, lda, i0, (kt + 2) * MK, M, K);
+      LoadSlab<CB, true>(rb, B, ldb, j0, (kt + 2) * MK, N, K);
+      __builtin_amdgcn_sched_barrier(0);  // do not let the scheduler sink these loads
+    } else {
+      load(kt + 2);
+    }
+  };
+  load(0);
+  StoreSlab<CA>(As[0], ra);
+  StoreSlab<CB>(Bs[0], rb);
+  __syncthreads();
+  load(1);
+  int64_t kt = 0;
+  for (; kt + 2 < nfull; ++kt) slab(std::true_type(), kt);
+  for (; kt < nk; ++kt) slab(std::false_type(), kt);
 
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
