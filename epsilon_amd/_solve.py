@@ -269,8 +269,8 @@ def profile_dump():
 # ---- per-operator entry points ------------------------------------------------------------------
 
 
-def linear_map_apply(lmap, x, transpose=False):
-    """y = A x (or A^T x) for an `ir.LMap`."""
+def linear_map_apply(lmap, x, transpose=False, inverse=False):
+    """y = A x (or A^T x, or A^-1 x through the explicit inverse map) for an `ir.LMap`."""
     L = lib()
     keep = []
     blobs, nb = _blobs(lmap.data, keep)
@@ -279,7 +279,8 @@ def linear_map_apply(lmap, x, transpose=False):
     ny = lmap.n if transpose else lmap.m
     y = np.empty(ny, dtype=np.float64)
     _check(L.eps_linear_map_apply(pbytes, ctypes.c_size_t(len(pbytes)), blobs,
-                                  ctypes.c_size_t(nb), ctypes.c_int(1 if transpose else 0),
+                                  ctypes.c_size_t(nb),
+                                  ctypes.c_int((1 if transpose else 0) | (2 if inverse else 0)),
                                   x.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(x.size),
                                   y.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(ny)))
     return y

@@ -348,7 +348,8 @@ int eps_linear_map_apply(const void* linear_map, size_t len, const eps_blob* dat
     SetCurrentDType(dt);
     auto dm = MakeDataMap(data, ndata, dt);
     LinearMap A = ParseMap(linear_map, len, dm.get());
-    if (transpose) A = A.Transpose();
+    if (transpose & 1) A = A.Transpose();
+    if (transpose & 2) A = A.Inverse();  // apply the (cached, explicit) inverse map
     EPS_CHECK_MSG(static_cast<int64_t>(nx) == A.impl().n() && static_cast<int64_t>(ny) == A.impl().m(),
                   "map is " << A.impl().m() << " x " << A.impl().n() << ", got x of " << nx
                             << " and y of " << ny);
@@ -442,6 +443,11 @@ int eps_bench_gemv(int trans, int64_t rows, int64_t cols, int iters, double* ms_
     DVec A = Synthetic(rows * cols, dt, 1.0);
     DVec x = Synthetic(trans ? rows : cols, dt, 1.0);
     DVec y = DVec::Zeros(trans ? cols : rows, dt);
+    if (trans == 2) {  // symmetric apply (reads the lower tiles only)
+      EPS_CHECK(rows == cols);
+      *ms_avg = TimeLaunches(iters, [&] { k::Symv(rows, 1.0, A, rows, x, 0.0, y); });
+      return;
+    }
     *ms_avg = TimeLaunches(iters, [&] { k::Gemv(trans != 0, rows, cols, 1.0, A, rows, x, 0.0, y); });
   });
 }

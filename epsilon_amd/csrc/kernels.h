@@ -35,6 +35,11 @@ void Dot(const DVec& x, const DVec& y, double* slot, bool accumulate);
 void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, int64_t lda,
           const DVec& x, double beta, const DVec& y);
 
+// y = alpha * S x + beta * y for a symmetric S in full storage (n x n, leading dimension lds):
+// reads only the lower-triangle tiles, half the bytes of Gemv.
+void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, double beta,
+          const DVec& y);
+
 // y[r] = alpha * sum_{k < nparts} partial[k*rows + r] + beta*y[r], fixed summation order.
 void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
                     const DVec& y);

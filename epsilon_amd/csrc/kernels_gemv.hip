@@ -358,7 +358,172 @@ void LaunchGemvT(int64_t rows, int64_t cols, double alpha, const T* A, int64_t l
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Symv: y = alpha * S x + beta * y for a SYMMETRIC S held in full storage, reading only the
+// tiles on and below the diagonal - half the bytes of a GEMV.  The cached explicit inverse of a
+// least-squares prox (K3) is such a matrix and its apply is ~1/6 of a lasso sweep.
+//
+// One workgroup per 128 x 128 tile (I >= J).  A thread owns 16 rows (four 16-byte loads per
+// column) of 4 columns.  Off-diagonal tiles contribute twice: y_I += T x_J (row sums, reduced
+// over the 32 column groups through LDS) and y_J += T^T x_I (column sums, reduced over the 8
+// row groups with three shuffle steps).  Both land in per-tile partial
+// vectors that SymvReduceKernel adds in a fixed order, so the result is deterministic.
+// ------------------------------------------------------------------------------------------
+constexpr int kSB = 128;
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void SymvTileKernel(int64_t n, const T* __restrict__ S,
+                                                         int64_t lds, const T* __restrict__ x,
+                                                         T* __restrict__ prow,
+                                                         T* __restrict__ pcol) {
+  __shared__ T xI[kSB], xJ[kSB];
+  __shared__ T red[32][kSB];
+  // tile (I, J) from the linear index over the lower triangle
+  const int64_t lin = blockIdx.x;
+  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+  while (I * (I + 1) / 2 > lin) --I;
+  const int64_t J = lin - I * (I + 1) / 2;
+  const int64_t i0 = I * kSB, j0 = J * kSB;
+  const int t = threadIdx.x;
+  if (t < kSB) {
+    xI[t] = (i0 + t < n) ? x[i0 + t] : T(0);
+  } else {
+    const int c = t - kSB;
+    xJ[c] = (j0 + c < n) ? x[j0 + c] : T(0);
+  }
+  __syncthreads();
+  // thread (rg, cg): rows 4*(rg + 8q) + v (q, v < 4) of columns cg + 32k (k < 4).  Column sums
+  // then need only 3 shuffle steps over the 8 row groups; row sums go through LDS.
+  const int rg = t & 7, cg = t >> 3;
+  const bool full = (i0 + kSB <= n) && (j0 + kSB <= n) && (lds % 4 == 0) &&
+                    (reinterpret_cast<uintptr_t>(S) % 16 == 0);
+  T a[4][4][4];  // [k][q][v]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = cg + 32 * k;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * (rg + 8 * q);
+      const T* src = S + (i0 + r) + (j0 + c) * lds;
+      if (full) {
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(a[k][q]) = *reinterpret_cast<const float4*>(src);
+        } else {
+          *reinterpret_cast<double2*>(&a[k][q][0]) = *reinterpret_cast<const double2*>(src);
+          *reinterpret_cast<double2*>(&a[k][q][2]) = *reinterpret_cast<const double2*>(src + 2);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          a[k][q][v] = (i0 + r + v < n && j0 + c < n) ? src[v] : T(0);
+      }
+    }
+  }
+  // row sums over this thread's 4 columns, then over the 32 column groups through LDS
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      T rs = T(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rs += a[k][q][v] * xJ[cg + 32 * k];
+      red[cg][4 * (rg + 8 * q) + v] = rs;
+    }
+  }
+  // column sums (off-diagonal tiles only) over this thread's 16 rows, then over the 8 row groups
+  if (I != J) {
+    T xr[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) xr[q][v] = xI[4 * (rg + 8 * q) + v];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      T cs = T(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) cs += a[k][q][v] * xr[q][v];
+      cs += __shfl_xor(cs, 1, 64);
+      cs += __shfl_xor(cs, 2, 64);
+      cs += __shfl_xor(cs, 4, 64);
+      if (rg == 0) pcol[lin * kSB + cg + 32 * k] = cs;
+    }
+  }
+  __syncthreads();
+  if (t < kSB) {
+    T s = red[0][t];
+#pragma unroll
+    for (int g = 1; g < 32; ++g) s += red[g][t];
+    prow[lin * kSB + t] = s;
+  }
+}
+
+// y[r] = alpha * (sum_{J <= I} prow[(I,J)][r] + sum_{I' > I} pcol[(I',I)][r]) + beta * y[r].
+// One workgroup per block of 128 rows; the nb partial vectors of a block are dealt to two
+// half-workgroups (even / odd position in the list), loaded eight at a time, and the two halves
+// are added in a fixed order.
+template <class T>
+__global__ __launch_bounds__(kBlock) void SymvReduceKernel(int64_t n, int64_t nb,
+                                                           const T* __restrict__ prow,
+                                                           const T* __restrict__ pcol, T alpha,
+                                                           T beta, T* y) {
+  __shared__ T half[kSB];
+  const int64_t I = blockIdx.x;
+  const int off = threadIdx.x & (kSB - 1), grp = threadIdx.x >> 7;  // kSB == 128
+  const int64_t base = I * (I + 1) / 2;
+  auto part = [&](int64_t p) -> const T* {  // p-th partial vector of this block, p < nb
+    return p <= I ? prow + (base + p) * kSB : pcol + (p * (p + 1) / 2 + I) * kSB;
+  };
+  T s = T(0);
+  int64_t p = grp;
+  for (; p + 14 < nb; p += 16) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part(p + 2 * u)[off];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < nb; p += 2) s += part(p)[off];
+  if (grp == 1) half[off] = s;
+  __syncthreads();
+  const int64_t r = I * kSB + off;
+  if (grp == 0 && r < n) {
+    const T tot = s + half[off];
+    y[r] = (beta == T(0)) ? alpha * tot : alpha * tot + beta * y[r];
+  }
+}
+
+template <class T>
+void LaunchSymv(int64_t n, double alpha, const T* S, int64_t lds, const T* x, double beta, T* y) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  const int64_t nb = (n + kSB - 1) / kSB;
+  const int64_t ntiles = nb * (nb + 1) / 2;
+  auto buf = rt.Alloc(static_cast<size_t>(2 * ntiles * kSB) * sizeof(T));
+  T* prow = static_cast<T*>(buf->p);
+  T* pcol = prow + ntiles * kSB;
+  hipLaunchKernelGGL((SymvTileKernel<T>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, s,
+                     n, S, lds, x, prow, pcol);
+  static_assert(kSB == 128 && kBlock == 256, "SymvReduceKernel geometry");
+  hipLaunchKernelGGL((SymvReduceKernel<T>), dim3(static_cast<unsigned>(nb)), dim3(kBlock), 0, s, n,
+                     nb, prow, pcol, T(alpha), T(beta), y);
+}
+
 }  // namespace
+
+void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, double beta,
+          const DVec& y) {
+  EPS_CHECK(S.dt == x.dt && S.dt == y.dt && x.n == n && y.n == n && lds >= n);
+  EPS_CHECK_MSG(n == 0 || S.n >= (n - 1) * lds + n, "symv: matrix buffer too small");
+  EPS_CHECK_MSG(x.data() != y.data(), "symv: x and y alias");
+  if (n == 0) return;
+  ProfScope prof("symv", n);
+  if (S.dt == F32) LaunchSymv<float>(n, alpha, S.as<float>(), lds, x.as<float>(), beta, y.as<float>());
+  else LaunchSymv<double>(n, alpha, S.as<double>(), lds, x.as<double>(), beta, y.as<double>());
+  EPS_HIP(hipGetLastError());
+}
 
 void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
                     const DVec& y) {

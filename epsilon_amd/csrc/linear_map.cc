@@ -237,7 +237,7 @@ std::string DenseMatrixImpl::DebugString() const {
   return os.str();
 }
 std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Transpose() const {
-  return std::make_shared<DenseMatrixImpl>(data_, rows_, cols_, !trans_, scale_, id_);
+  return std::make_shared<DenseMatrixImpl>(data_, rows_, cols_, !trans_, scale_, id_, symmetric_);
 }
 DVec DenseMatrixImpl::Materialize(bool force_copy) const {
   if (!trans_ && scale_ == 1.0 && !force_copy) return data_;
@@ -264,12 +264,12 @@ std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Inverse() const {
   if (cache && id_) {
     key = HashDouble(HashCombine(HashCombine(id_, 0x1171), trans_ ? 2 : 1), scale_);
     if (auto hit = cache->Find(key))
-      return std::make_shared<DenseMatrixImpl>(hit->data(), nn, nn, false, sign, key);
+      return std::make_shared<DenseMatrixImpl>(hit->data(), nn, nn, false, sign, key, true);
   }
   DVec W = DVec::Empty(nn * nn, data_.dt);
   k::MatCopy(trans_, nn, nn, sign * scale_, data_, rows_, W);
   k::SpdInverseInPlace(W, nn);
-  auto result = std::make_shared<DenseMatrixImpl>(W, nn, nn, false, sign, key);
+  auto result = std::make_shared<DenseMatrixImpl>(W, nn, nn, false, sign, key, true);
   if (cache && key) cache->Put(key, result);
   return result;
 }
@@ -287,6 +287,10 @@ bool DenseMatrixImpl::Equals(const LinearMapImpl& o) const {
   return rt.SlotValue(s) == 0.0;
 }
 void DenseMatrixImpl::Apply(double alpha, const DVec& x, double beta, const DVec& y) const {
+  if (symmetric_ && rows_ >= 1024) {  // half the bytes; below that the two launches cost more
+    k::Symv(rows_, alpha * scale_, data_, rows_, x, beta, y);
+    return;
+  }
   k::Gemv(trans_, rows_, cols_, alpha * scale_, data_, rows_, x, beta, y);
 }
 std::vector<double> DenseMatrixImpl::AsDenseHost() const { return Materialize(false).ToHost(); }
@@ -514,7 +518,7 @@ ImplPtr Multiply(const LinearMapImpl& L, const LinearMapImpl& R) {
       case DENSE_MATRIX: {
         const auto& D = static_cast<const DenseMatrixImpl&>(R);
         return std::make_shared<DenseMatrixImpl>(D.data(), D.rows(), D.cols(), D.trans(),
-                                                 S.alpha() * D.scale(), D.id());
+                                                 S.alpha() * D.scale(), D.id(), D.symmetric());
       }
       case KRONECKER_PRODUCT:
         return MultiplyScalarKron(S, static_cast<const KroneckerProductImpl&>(R));
@@ -533,7 +537,7 @@ ImplPtr Multiply(const LinearMapImpl& L, const LinearMapImpl& R) {
       case DENSE_MATRIX: {
         const auto& D = static_cast<const DenseMatrixImpl&>(L);
         return std::make_shared<DenseMatrixImpl>(D.data(), D.rows(), D.cols(), D.trans(),
-                                                 D.scale() * S.alpha(), D.id());
+                                                 D.scale() * S.alpha(), D.id(), D.symmetric());
       }
       case KRONECKER_PRODUCT:  // reference :223-227 delegates with swapped arguments
         return MultiplyScalarKron(S, static_cast<const KroneckerProductImpl&>(L));

@@ -171,10 +171,12 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   // `id` names the CONTENT of the buffer (0 = anonymous).  Results of the setup algebra get ids
   // derived from their operands' ids, so a later Init with the same matrices (warm start,
   // re-bound vector parameters) finds them in the OpCache instead of redoing GEMM / inverse.
+  // `symmetric`: the buffer is known to be exactly symmetric (an explicit inverse of a
+  // symmetric matrix); Apply then reads only half of it (k::Symv).
   DenseMatrixImpl(DVec data, int64_t rows, int64_t cols, bool trans, double scale,
-                  uint64_t id = 0)
+                  uint64_t id = 0, bool symmetric = false)
       : LinearMapImpl(DENSE_MATRIX), data_(std::move(data)), rows_(rows), cols_(cols),
-        trans_(trans), scale_(scale), id_(id) {}
+        trans_(trans), scale_(scale), id_(id), symmetric_(symmetric && rows == cols) {}
   int64_t m() const override { return trans_ ? cols_ : rows_; }
   int64_t n() const override { return trans_ ? rows_ : cols_; }
   std::string DebugString() const override;
@@ -190,6 +192,7 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   bool trans() const { return trans_; }
   double scale() const { return scale_; }
   uint64_t id() const { return id_; }
+  bool symmetric() const { return symmetric_; }
   DType dtype() const { return data_.dt; }
   // Contiguous m() x n() buffer holding scale*op(data) (a fresh copy unless already plain).
   DVec Materialize(bool force_copy) const;
@@ -200,6 +203,7 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   bool trans_;
   double scale_;
   uint64_t id_;
+  bool symmetric_;
 };
 
 // Memo of dense setup results (Gram products, sums, explicit inverses) keyed by content id.

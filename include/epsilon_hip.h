@@ -147,7 +147,9 @@ int eps_profile_dump(char* buf, size_t cap);
 /* ---- per-operator entry points (parity tests pin each kernel through these) ----------------- */
 
 /* y = op(A) x for a serialized `LinearMap` (reference linear/linear_map.cc:83-104 +
- * LinearMapImpl::Apply); transpose != 0 applies the adjoint.  x, y: host float64. */
+ * LinearMapImpl::Apply); `transpose` is a bit set: 1 applies the adjoint, 2 applies the map's
+ * Inverse() (reference LinearMapImpl::Inverse, e.g. dense_matrix_impl.cc:21-30).
+ * x, y: host float64. */
 int eps_linear_map_apply(const void* linear_map, size_t len, const eps_blob* data, size_t ndata,
                          int transpose, const double* x, size_t nx, double* y, size_t ny);
 /* C = A op B with op = '+' or '*' through the type-dispatch tables (reference

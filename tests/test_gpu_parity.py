@@ -193,6 +193,21 @@ def test_dense_inverse(solve_mod, dtype, n, sign):
     np.testing.assert_allclose(inv, ref, **tol)
 
 
+@pytest.mark.parametrize("n", [1024, 1300, 2049])
+def test_cached_inverse_apply_symmetric_kernel(solve_mod, dtype, n):
+    """The explicit inverse of a symmetric matrix is applied by the half-traffic symmetric
+    kernel (k::Symv) from n = 1024 up: y = W^-1 x against a dense solve, sizes that end in
+    partial 128 x 128 tiles included."""
+    rng = np.random.RandomState(n)
+    G = rng.randn(n, n + 7) / np.sqrt(n)
+    W = np.eye(n) + G.dot(G.T)
+    x = rng.randn(n)
+    got = solve_mod.linear_map_apply(ir.dense_matrix(W), x, inverse=True)
+    want = np.linalg.solve(W, x)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(got, want, **tol)
+
+
 def test_gemm_mfma_vs_oracle(solve_mod):
     """Dense*Dense through the f32 MFMA kernel (all four transpose combinations, ragged
     edges) vs numpy."""

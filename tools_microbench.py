@@ -16,8 +16,8 @@ def gemv(trans, rows, cols, iters=50, dtype="f32"):
     _solve._check(L.eps_bench_gemv(ctypes.c_int(trans), ctypes.c_int64(rows), ctypes.c_int64(cols),
                                    ctypes.c_int(iters), ctypes.byref(ms)))
     sz = 4 if dtype == "f32" else 8
-    print("gemv_%s %dx%d %s: %.4f ms  %.0f GB/s" % ("t" if trans else "n", rows, cols, dtype, ms.value,
-                                                  rows * cols * sz / ms.value / 1e6), flush=True)
+    print("gemv_%s %dx%d %s: %.4f ms  %.0f GB/s (dense bytes)" % (["n", "t", "sym"][trans], rows, cols, dtype,
+                                                                ms.value, rows * cols * sz / ms.value / 1e6), flush=True)
 
 
 def gemm(ta, tb, M, N, K, lower=0, iters=3, dtype="f32"):
@@ -44,6 +44,7 @@ if __name__ == "__main__":
         gemv(1, 10000, 50000)
         gemv(0, 10000, 10000)
         gemv(1, 10000, 10000)
+        gemv(2, 10000, 10000)
         gemv(0, 10000, 6272)
         gemv(1, 10000, 6272)
     if "gemm" in what:
