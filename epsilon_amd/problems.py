@@ -18,6 +18,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import ir
+from . import wire
 from .wire import ProxFunction
 
 
@@ -261,3 +262,96 @@ def covsel(n, m=None, lam=0.1, seed=0):
 def covsel_objective(S, lam, X):
     sign, logdet = np.linalg.slogdet(X)
     return float(-logdet + np.sum(S * X) + lam * np.abs(X).sum()) if sign > 0 else float("inf")
+
+
+# ---- LP-representable benchmark problems in graph form (reference python/epopt/problems/
+#      basis_pursuit.py, least_abs_dev.py, lp.py, hinge_l1.py, quantile.py) -------------------------
+# Each data-dependent affine relation z = C x (+ d) is one ZERO term over private copies
+# (x', z'), tied to the variables of the separable terms by consensus constraints - the shape
+# the reference's compiler produces (compiler/transforms/separate.py).
+
+
+def _graph_form(f_terms, C, d, x_key="var:x", z_key="var:z", x_in_terms=True):
+    """terms(x, z) + zero(C x' - z' + d)  s.t.  x' - x = 0, z' - z = 0  (d may be None).  When no
+    separable term touches x (`x_in_terms=False`) it lives in the ZERO term alone, uncopied."""
+    m, n = C.shape
+    x = ir.variable(n, 1, x_key)
+    z = ir.variable(m, 1, z_key)
+    xp = ir.variable(n, 1, "separate:%s:zero" % x_key) if x_in_terms else x
+    zp = ir.variable(m, 1, "separate:%s:zero" % z_key)
+    parts = [ir.linear_map(ir.dense_matrix(C), xp), ir.linear_map(ir.scalar(-1, m), zp)]
+    if d is not None:
+        parts.append(ir.constant(np.asarray(d, dtype=np.float64)))
+    terms = list(f_terms(x, z)) + [ir.prox(ProxFunction.ZERO, ir.add(*parts))]
+    cons = [ir.zero(ir.add(zp, ir.linear_map(ir.scalar(-1, m), z)))]
+    if x_in_terms:
+        cons.insert(0, ir.zero(ir.add(xp, ir.linear_map(ir.scalar(-1, n), x))))
+    return ir.Problem(terms, cons)
+
+
+def basis_pursuit(m, n, seed=0):
+    """min ||x||_1  s.t.  A x = b."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    b = A.dot(rng.randn(n) * (rng.rand(n) < 0.2))
+    xp = ir.variable(n, 1, "separate:var:x:zero")
+    x = ir.variable(n, 1, "var:x")
+    f0 = ir.prox(ProxFunction.NORM_1, x)
+    f1 = ir.prox(ProxFunction.ZERO, ir.add(ir.linear_map(ir.dense_matrix(A), xp),
+                                           ir.linear_map(ir.scalar(-1, m), ir.constant(b))))
+    c = ir.zero(ir.add(xp, ir.linear_map(ir.scalar(-1, n), x)))
+    return ir.Problem([f0, f1], [c]), dict(A=A, b=b)
+
+
+def least_abs_dev(m, n, seed=0):
+    """min ||A x - b||_1: norm_1(z) with z = A x - b."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    b = A.dot(rng.randn(n)) + rng.laplace(size=m)
+    prob = _graph_form(lambda x, z: [ir.prox(ProxFunction.NORM_1, z)], A, -b, x_in_terms=False)
+    return prob, dict(A=A, b=b)
+
+
+def hinge_l1(m, n, lam=None, seed=0):
+    """sum_i max(0, 1 - y_i a_i^T x) + lam ||x||_1: sum_hinge(1 - z) with z = diag(y) A x."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    y = np.sign(A.dot(rng.randn(n) * (rng.rand(n) < 0.3)) + 0.1 * rng.randn(m))
+    C = y[:, None] * A
+    if lam is None:
+        lam = 0.1 * np.abs(C.sum(axis=0)).max()
+
+    def terms(x, z):
+        arg = ir.add(ir.linear_map(ir.scalar(-1, m), z), ir.scalar_constant(1.0, (m, 1)))
+        return [ir.prox(ProxFunction.SUM_HINGE, arg), ir.prox(ProxFunction.NORM_1, x, alpha=lam)]
+    return _graph_form(terms, C, None), dict(C=C, lam=lam)
+
+
+def quantile(m, n, tau=0.3, seed=0):
+    """Quantile regression sum_i rho_tau(b_i - a_i^T x): sum_quantile(z), z = A x - b, with
+    alpha = 1 - tau on the positive and beta = tau on the negative part of z."""
+    rng = np.random.RandomState(seed)
+    A = np.hstack([np.ones((m, 1)), rng.randn(m, n - 1)])
+    b = A.dot(rng.randn(n)) + rng.randn(m) * (1 + np.abs(A[:, 1]))
+    qa, qb = ir.scalar_constant(1.0 - tau, (1, 1)), ir.scalar_constant(tau, (1, 1))
+
+    def terms(x, z):
+        return [ir.prox(ProxFunction.SUM_QUANTILE, z,
+                        scaled_zone_params=wire.ProxScaledZoneParams(alpha_expr=qa.proto,
+                                                                     beta_expr=qb.proto))]
+    return _graph_form(terms, A, -b, x_in_terms=False), dict(A=A, b=b, tau=tau)
+
+
+def lp(m, n, seed=0):
+    """min c^T x  s.t.  A x <= b  (bounded, feasible):  affine(c^T x) + non_negative(s) with
+    s = b - A x."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    x0 = rng.randn(n)
+    b = A.dot(x0) + rng.rand(m)
+    c = -A.T.dot(rng.rand(m))  # c in -cone(A^T): the LP is bounded
+
+    def terms(x, s):
+        return [ir.prox(ProxFunction.AFFINE, ir.linear_map(ir.dense_matrix(c.reshape(1, -1)), x)),
+                ir.prox(ProxFunction.NON_NEGATIVE, s)]
+    return _graph_form(terms, -A, b, z_key="var:s"), dict(A=A, b=b, c=c)

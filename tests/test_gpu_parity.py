@@ -413,6 +413,23 @@ def test_multiclass_hinge_problem(solve_mod, dtype):
         np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
 
 
+@pytest.mark.parametrize("name", ["basis_pursuit", "least_abs_dev", "hinge_l1", "quantile", "lp"])
+def test_lp_type_problems(solve_mod, dtype, name):
+    """Graph-form problems over ZERO / AFFINE / NON_NEGATIVE / NORM_1 / SUM_HINGE / SUM_QUANTILE
+    (reference solve_test.py:26-48): same stopping iteration and iterates as the oracle."""
+    prob, info = {"basis_pursuit": lambda: problems.basis_pursuit(10, 30),
+                  "least_abs_dev": lambda: problems.least_abs_dev(30, 5),
+                  "hinge_l1": lambda: problems.hinge_l1(40, 10),
+                  "quantile": lambda: problems.quantile(40, 3),
+                  "lp": lambda: problems.lp(20, 8)}[name]()
+    params = wire.SolverParams(max_iterations=80)
+    sg, xg, so, xo = solve_both(solve_mod, prob, params)
+    assert sg.num_iterations == so.num_iterations and sg.state == so.state
+    tol = dict(rtol=1e-6, atol=1e-8) if dtype == "f64" else dict(rtol=5e-3, atol=5e-3)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
+
+
 @pytest.mark.parametrize("name", ["group_lasso", "logreg_l1", "covsel"])
 def test_more_benchmark_problems(solve_mod, dtype, name):
     """Drivers over the batched NORM_2 (group lasso), SUM_LOGISTIC + ZERO graph form (l1 logistic

@@ -146,3 +146,64 @@ def test_covsel_problem():  # NEG_LOG_DET on the symmetric part
     G = info["S"] - np.linalg.inv(X)
     assert np.all(np.abs(G) <= info["lam"] + 5e-2)
     assert obj < problems.covsel_objective(info["S"], info["lam"], np.eye(6))
+
+
+# ---- LP-representable problems: scipy's linprog gives the exact optimum -------------------------
+
+
+def test_basis_pursuit_problem():  # solve_test.py:26
+    prob, info = problems.basis_pursuit(10, 30)
+    S, x = solve(prob, max_iterations=2000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    A, b = info["A"], info["b"]
+    r = optimize.linprog(np.ones(60), A_eq=np.hstack([A, -A]), b_eq=b, bounds=(0, None))
+    assert np.abs(x["var:x"]).sum() <= r.fun * (1 + 1e-2) + 1e-4
+    assert np.abs(A @ x["var:x"] - b).max() < 5e-2
+
+
+def test_least_abs_dev_problem():  # solve_test.py:38
+    prob, info = problems.least_abs_dev(30, 5)
+    S, x = solve(prob, max_iterations=2000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    A, b = info["A"], info["b"]
+    m, n = A.shape
+    r = optimize.linprog(np.r_[np.zeros(n), np.ones(m)],
+                         A_ub=np.block([[A, -np.eye(m)], [-A, -np.eye(m)]]), b_ub=np.r_[b, -b],
+                         bounds=[(None, None)] * n + [(0, None)] * m)
+    assert np.abs(A @ x["var:x"] - b).sum() <= r.fun * (1 + 1e-2) + 1e-4
+
+
+def test_hinge_l1_problem():  # solve_test.py:30
+    prob, info = problems.hinge_l1(40, 10)
+    S, x = solve(prob, max_iterations=2000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    C, lam = info["C"], info["lam"]
+    m, n = C.shape
+    obj = np.maximum(0, 1 - C @ x["var:x"]).sum() + lam * np.abs(x["var:x"]).sum()
+    r = optimize.linprog(np.r_[lam * np.ones(2 * n), np.ones(m)],
+                         A_ub=np.hstack([-C, C, -np.eye(m)]), b_ub=-np.ones(m), bounds=(0, None))
+    assert obj <= r.fun * (1 + 1e-2) + 1e-4
+
+
+def test_quantile_problem():  # solve_test.py:48
+    prob, info = problems.quantile(40, 3)
+    S, x = solve(prob, max_iterations=2000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    A, b, tau = info["A"], info["b"], info["tau"]
+    m, n = A.shape
+    z = A @ x["var:x"] - b
+    obj = ((1 - tau) * np.maximum(z, 0) + tau * np.maximum(-z, 0)).sum()
+    r = optimize.linprog(np.r_[np.zeros(n), (1 - tau) * np.ones(m), tau * np.ones(m)],
+                         A_eq=np.hstack([A, -np.eye(m), np.eye(m)]), b_eq=b,
+                         bounds=[(None, None)] * n + [(0, None)] * (2 * m))
+    assert obj <= r.fun * (1 + 1e-2) + 1e-4
+
+
+def test_lp_problem():  # solve_test.py:41
+    prob, info = problems.lp(20, 8)
+    S, x = solve(prob, max_iterations=3000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    A, b, c = info["A"], info["b"], info["c"]
+    r = optimize.linprog(c, A_ub=A, b_ub=b, bounds=(None, None))
+    assert c @ x["var:x"] <= r.fun + 2e-2 * abs(r.fun) + 1e-4
+    assert (A @ x["var:x"] - b).max() < 5e-2
