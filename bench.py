@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--no-profile", action="store_true",
                    help="diagnostic: no HIP-event kernel timers in the timed region (no roofline)")
     p.add_argument("--profile-all", action="store_true", help="time every tagged kernel")
+    p.add_argument("--comm", default="rccl", choices=["rccl", "host"],
+                   help="host: rehearsal of the N > 1 path on fewer GPUs than ranks (gloo + "
+                        "host-callback collectives, ranks share devices) - not a judged configuration")
     p.add_argument("--force-sharded", action="store_true",
                    help="rehearsal on one GPU: run the sharded code path (RCCL communicator of "
                         "size 1) - not a judged configuration")
@@ -117,9 +120,14 @@ def main():
     from epsilon_amd import _solve, wire
 
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.comm == "host":
+        local_rank = local_rank % torch.cuda.device_count()
+        os.environ["EPSILON_HIP_DEVICE"] = str(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if args.force_sharded and world == 1:
+    if args.comm == "host" and world > 1:
+        dist.init_process_group("gloo")
+    elif args.force_sharded and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29653")
         os.environ["EPSILON_HIP_FORCE_SHARDED"] = "1"
@@ -134,7 +142,7 @@ def main():
     if sharded:
         from epsilon_amd import dist as edist
         cols = edist.column_range(n, rank, world)
-        edist.init_comm(rank, world)
+        edist.init_comm(rank, world, backend=args.comm)
     else:
         cols = None
     At, b, lam = make_instance(m, n, device, cols=cols)
@@ -142,6 +150,7 @@ def main():
     pb, data = prob.SerializeToString(), prob.expression_data()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
@@ -192,7 +201,7 @@ def main():
     prof = _solve.profile_dump()
     _solve.profile_enable(False)
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if args.comm == "rccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
