@@ -219,7 +219,7 @@ def main():
     # bytes are 2*m*n*s while it moves m*n*s.  Unfused path: K1 = A v, m*n*s.
     fused_tag = "lasso_fused:%dx%d" % (m, n_loc)
     if fused_tag in prof:
-        tag, kname = fused_tag, "LassoFusedKernel<10> (K2 of sweep k + prox chain + K1 of sweep k+1)"
+        tag, kname = fused_tag, "LassoFusedStreamKernel<10> (K2 of sweep k + prox chain + K1 of sweep k+1)"
         alg_bytes, moved = 2 * m * n_loc * sz, m * n_loc * sz
     else:
         tag, kname = "gemv_n:%dx%d" % (m, n_loc), "GemvNKernel<float,4> (K1: y = A v)"

@@ -16,10 +16,12 @@
 // to the unfused path.  HBM traffic per sweep drops from (2mn + m^2)s to (mn + m^2)s.
 //
 // Geometry: 256 threads own all m rows (thread t: rows 4(t + 256q), q < NR - 16 B loads,
-// coalesced 4 KiB per q); w and the partial t' stay in registers for the whole launch; columns
-// are processed in pairs so 2*NR loads per thread are in flight; the two dot products are
-// reduced with wave shuffles + LDS in a fixed order (deterministic); per-workgroup partial t'
-// vectors are summed by ReducePartials.
+// coalesced 4 KiB per q); w and the partial t' stay in registers for the whole launch; the dot
+// products are reduced with wave shuffles + LDS in a fixed order (deterministic); per-workgroup
+// partial t' vectors are summed by ReducePartials.  Two forms: LassoFusedKernel takes columns in
+// pairs (2*NR loads, then reduce / chain / update with nothing in flight);
+// LassoFusedStreamKernel (the default) takes one column per step with the next column's NR
+// loads already issued, so the memory pipe never drains.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -175,10 +177,106 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedKernel(
     if (row[q] < m) *reinterpret_cast<float4*>(out + row[q]) = tp[q];
 }
 
+// Streaming variant: ONE column per step, the next column already in flight.  The pair kernel
+// above issues 2*NR loads, waits for all of them and has nothing in flight while it reduces,
+// synchronises and runs the chain; here the loads of column j+1 are issued before the dot
+// product of column j is reduced, so every workgroup keeps NR 16-byte loads per lane outstanding
+// at all times.  Same arithmetic per column, bit-identical state.
+template <int NR>
+__global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
+    int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
+    FusedScalars c, float* u, float* x0, float* x1, float* y0, float* y1, float* y1prev,
+    float* __restrict__ tpart) {
+  __shared__ float red[2][kBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 wv[NR], tp[NR];
+  int64_t row[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    row[q] = (static_cast<int64_t>(q) * kBlock + tid) * 4;
+    wv[q] = row[q] < m ? *reinterpret_cast<const float4*>(w + row[q]) : make_float4(0, 0, 0, 0);
+    tp[q] = make_float4(0, 0, 0, 0);
+  }
+  // this workgroup's columns: the same pairs the pair kernel would take, one column at a time
+  const int64_t npairs = (n + 1) / 2;
+  auto column = [&](int64_t step) -> int64_t {  // step -> column index, or -1 past the end
+    const int64_t jp = blockIdx.x + (step >> 1) * gridDim.x;
+    const int64_t j = 2 * jp + (step & 1);
+    return (jp < npairs && j < n) ? j : -1;
+  };
+  auto load = [&](float4 (&a)[NR], int64_t j) {
+    const float* cp = A + j * lda;
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      a[q] = row[q] < m ? *reinterpret_cast<const float4*>(cp + row[q]) : make_float4(0, 0, 0, 0);
+  };
+  float4 cur[NR], nxt[NR];
+  int64_t step = 0;
+  int64_t j = column(0);
+  if (j >= 0) load(cur, j);
+  int par = 0;
+  while (j >= 0) {
+    // skip the odd slot of a trailing unpaired column without breaking the sequence
+    int64_t jn = column(step + 1);
+    if (jn < 0 && ((step + 1) & 1)) jn = column(step + 2);
+    const int64_t step_n = (jn >= 0 && column(step + 1) < 0) ? step + 2 : step + 1;
+    if (jn >= 0) load(nxt, jn);
+    const float uj = u[j], y0j = y0[j], y1j = y1[j];
+    float d = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      d += cur[q].x * wv[q].x;
+      d += cur[q].y * wv[q].y;
+      d += cur[q].z * wv[q].z;
+      d += cur[q].w * wv[q].w;
+    }
+    d = WaveSumF(d);
+    if (lane == 0) red[par][wave] = d;
+    __syncthreads();
+    d = ((red[par][0] + red[par][1]) + red[par][2]) + red[par][3];
+    par ^= 1;
+    float nx0, nx1, ny0, ny1, nu;
+    const float v0n = ChainOne(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
+    if (tid == 0) {
+      y1prev[j] = y1j;
+      x0[j] = nx0;
+      x1[j] = nx1;
+      y0[j] = ny0;
+      y1[j] = ny1;
+      u[j] = nu;
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      tp[q].x += cur[q].x * v0n;
+      tp[q].y += cur[q].y * v0n;
+      tp[q].z += cur[q].z * v0n;
+      tp[q].w += cur[q].w * v0n;
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) cur[q] = nxt[q];
+    j = jn;
+    step = step_n;
+  }
+  float* out = tpart + static_cast<int64_t>(blockIdx.x) * m;
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    if (row[q] < m) *reinterpret_cast<float4*>(out + row[q]) = tp[q];
+}
+
 template <int NR>
 void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, const float* w,
                  const FusedScalars& c, float* u, float* x0, float* x1, float* y0, float* y1,
                  float* y1prev, float* tpart) {
+  // default: the streaming kernel (6.0 vs 5.75 TB/s on the 1e4 x 5e4 matrix); "pair" selects the
+  // two-column form
+  static const char* env = std::getenv("EPSILON_HIP_FUSED_KERNEL");
+  const bool stream = !(env && env[0] == 'p');
+  if (stream) {
+    hipLaunchKernelGGL(LassoFusedStreamKernel<NR>, dim3(grid), dim3(kBlock), 0,
+                       Runtime::Get().stream(), m, n, A, lda, w, c, u, x0, x1, y0, y1, y1prev,
+                       tpart);
+    return;
+  }
   hipLaunchKernelGGL(LassoFusedKernel<NR>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), m,
                      n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart);
 }

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 databases written by tools_profile.sh (gpurun_out/prof_*/…_results.db) into
+the summaries kept under profiles/: per-kernel duration statistics, per-kernel FETCH_SIZE /
+WRITE_SIZE averages, and profiles/traffic.json (HBM bytes per launch of the dominant kernel,
+2*FETCH_SIZE*1024 + WRITE_SIZE*1024 with the gfx950 FETCH_SIZE x2 correction of
+MI355X_MICROARCH.md).
+
+    python tools_profile_summarize.py <tag>      # e.g. r01c -> profiles/r01c_*.csv
+"""
+import csv
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0][:110]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+    prof = os.path.join(ROOT, "profiles")
+    con = sqlite3.connect(os.path.join(OUT, "prof_stats", "stats_results.db"))
+    rows = list(con.execute("select name,total_calls,total_duration,average,percentage "
+                            "from top_kernels order by total_duration desc"))
+    with open(os.path.join(prof, "%s_bench_default_kernel_stats.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+        for n, c, t, a, p in rows[:40]:
+            w.writerow([short(n), c, "%.3f" % t, "%.3f" % a, "%.2f" % p])
+    counters = {}
+    for nm, db in (("FETCH_SIZE", "prof_fetch/fetch_results.db"),
+                   ("WRITE_SIZE", "prof_write/write_results.db")):
+        c = sqlite3.connect(os.path.join(OUT, db))
+        q = ("select kernel_name, count(*), avg(value), min(value), max(value) from "
+             "counters_collection where counter_name=? group by kernel_name")
+        for kn, cnt, av, mn, mx in c.execute(q, (nm,)):
+            counters.setdefault(short(kn), {})[nm] = (cnt, av, mn, mx)
+    with open(os.path.join(prof, "%s_pmc_fetch_write_summary.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "Counter", "Launches", "AvgKB", "MinKB", "MaxKB"])
+        for k in sorted(counters):
+            if k.startswith("eps::"):
+                for nm, (cnt, av, mn, mx) in sorted(counters[k].items()):
+                    w.writerow([k, nm, cnt, "%.2f" % av, "%.2f" % mn, "%.2f" % mx])
+    fused = [k for k in counters if "LassoFused" in k and "FETCH_SIZE" in counters[k]]
+    fused.sort(key=lambda k: -counters[k]["FETCH_SIZE"][0])
+    fk = fused[0]
+    fetch, write = counters[fk]["FETCH_SIZE"][1], counters[fk]["WRITE_SIZE"][1]
+    bench = json.loads(open(os.path.join(OUT, "bench_default.json")).read().strip().splitlines()[-1])
+    key = [k for k in bench["kernels"] if k.startswith("lasso_fused")][0]
+    traffic = {key: 2 * fetch * 1024 + write * 1024, "_kernel": fk,
+               "_fetch_KB": round(fetch, 2), "_write_KB": round(write, 2),
+               "_note": "HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (rocprofv3 --pmc, "
+                        "separate passes; gfx950 FETCH_SIZE x2 correction, MI355X_MICROARCH.md HBM "
+                        "section); source profiles/%s_pmc_fetch_write_summary.csv" % tag}
+    json.dump(traffic, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+    with open(os.path.join(prof, "%s_bench_default.json" % tag), "w") as f:
+        f.write(json.dumps(bench) + "\n")
+    trace = [r for r in rows if "LassoFused" in r[0]][0]
+    print("fused kernel: trace avg %.1f us (%d calls), live avg %.1f us; HBM traffic %.4g B/launch"
+          % (trace[3], trace[1], 1e3 * bench["roofline"]["avg_launch_ms"], traffic[key]))
+    print("bench: %.0f iter/s, init %.3f s, time-to-eps %.3f s" %
+          (bench["value"], bench.get("init_s", 0), bench.get("time_to_eps_s", 0)))
+
+
+if __name__ == "__main__":
+    main()
