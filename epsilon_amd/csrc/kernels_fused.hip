@@ -204,11 +204,25 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
     const int64_t j = 2 * jp + (step & 1);
     return (jp < npairs && j < n) ? j : -1;
   };
+  // The matrix is read once per sweep with no reuse: non-temporal loads keep it from evicting
+  // the cached inverse (K3 operand, 200 MB of tiles) from the 256 MB Infinity Cache.
+  static const bool kNT = true;
   auto load = [&](float4 (&a)[NR], int64_t j) {
     const float* cp = A + j * lda;
 #pragma unroll
-    for (int q = 0; q < NR; ++q)
-      a[q] = row[q] < m ? *reinterpret_cast<const float4*>(cp + row[q]) : make_float4(0, 0, 0, 0);
+    for (int q = 0; q < NR; ++q) {
+      if (row[q] < m) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        if (kNT) {
+          const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(cp + row[q]));
+          a[q] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+          a[q] = *reinterpret_cast<const float4*>(cp + row[q]);
+        }
+      } else {
+        a[q] = make_float4(0, 0, 0, 0);
+      }
+    }
   };
   float4 cur[NR], nxt[NR];
   int64_t step = 0;
