@@ -312,13 +312,19 @@ class ProxADMMSolver final : public Solver {
       k::Axpby(v0, -1.0, f.y1, 1.0);
       k::Axpby(v0, 1.0, f.y0, 1.0);
       L.Apply(-1.0, v0, 0.0, f.p);
-    } else {
-      k::ReducePartials(f.m, f.grid, f.tpart, -L.scale(), 0.0, f.p);
     }
     const ShardSpec& sh = ShardSpec::Get();
     const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
+    bool rhs_added = false;
+    if (!from_state) {
+      // unsharded: the constant part of the rhs rides in the reduction kernel (same rounding
+      // order as the separate axpy: sum first, then + rhs)
+      const bool fold = !sharded && f.ls.rhs_arg.n != 0;
+      k::ReducePartials(f.m, f.grid, f.tpart, -L.scale(), 0.0, f.p, fold ? &f.ls.rhs_arg : nullptr);
+      rhs_added = fold;
+    }
     if (sharded) Runtime::Get().comm()->AllReduceSum(f.p);
-    if (f.ls.rhs_arg.n != 0) k::Axpby(f.p, 1.0, f.ls.rhs_arg, 1.0);
+    if (f.ls.rhs_arg.n != 0 && !rhs_added) k::Axpby(f.p, 1.0, f.ls.rhs_arg, 1.0);
     const DenseMatrixImpl& D = *f.ls.Dinv_arg;
     Comm* comm = Runtime::Get().comm();
     if (sharded && comm->size() > 1 && !D.trans() && D.rows() == f.m) {

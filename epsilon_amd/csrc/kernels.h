@@ -41,8 +41,9 @@ void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, do
           const DVec& y);
 
 // y[r] = alpha * sum_{k < nparts} partial[k*rows + r] + beta*y[r], fixed summation order.
+// `add` (optional) is added to the result afterwards: y = (alpha*sum + beta*y) + add.
 void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
-                    const DVec& y);
+                    const DVec& y, const DVec* add = nullptr);
 
 // ---- fused lasso sweep: one pass over A per ADMM sweep (kernels_fused.hip) ------------------
 struct LassoFusedArgs {

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(kBlock) void GemvNKernel(int64_t rows, int64_t cols
 template <class T>
 __global__ __launch_bounds__(kBlock) void GemvNReduceKernel(int64_t rows, int nsplit,
                                                             const T* __restrict__ partial,
-                                                            T alpha, T beta, T* y) {
+                                                            T alpha, T beta, T* y,
+                                                            const T* __restrict__ add) {
   __shared__ T part[kBlock / 64][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t r = static_cast<int64_t>(blockIdx.x) * 64 + lane;
@@ -166,7 +167,9 @@ __global__ __launch_bounds__(kBlock) void GemvNReduceKernel(int64_t rows, int ns
   __syncthreads();
   if (wave == 0 && r < rows) {
     const T t = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-    y[r] = (beta == T(0)) ? alpha * t : alpha * t + beta * y[r];
+    T out = (beta == T(0)) ? alpha * t : alpha * t + beta * y[r];
+    if (add) out += add[r];
+    y[r] = out;
   }
 }
 
@@ -205,7 +208,7 @@ void LaunchGemvN(int64_t rows, int64_t cols, double alpha, const T* A, int64_t l
   if (nsplit > 1) {
     hipLaunchKernelGGL(GemvNReduceKernel<T>, dim3(static_cast<unsigned>((rows + 63) / 64)),
                        dim3(kBlock), 0, s, rows, static_cast<int>(nsplit), partial, T(alpha),
-                       T(beta), y);
+                       T(beta), y, static_cast<const T*>(nullptr));
   }
 }
 
@@ -555,8 +558,9 @@ void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, do
 }
 
 void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
-                    const DVec& y) {
+                    const DVec& y, const DVec* add) {
   EPS_CHECK(partial.dt == y.dt && y.n == rows && partial.n >= static_cast<int64_t>(nparts) * rows);
+  if (add) EPS_CHECK(add->n == rows && add->dt == y.dt);
   if (rows == 0) return;
   hipStream_t s = Runtime::Get().stream();
   ProfScope prof("reduce_partials", rows, nparts);
@@ -564,10 +568,11 @@ void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha,
   if (y.dt == F32)
     hipLaunchKernelGGL(GemvNReduceKernel<float>, dim3(grid), dim3(kBlock), 0, s, rows, nparts,
                        partial.as<float>(), static_cast<float>(alpha), static_cast<float>(beta),
-                       y.as<float>());
+                       y.as<float>(), add ? add->as<float>() : nullptr);
   else
     hipLaunchKernelGGL(GemvNReduceKernel<double>, dim3(grid), dim3(kBlock), 0, s, rows, nparts,
-                       partial.as<double>(), alpha, beta, y.as<double>());
+                       partial.as<double>(), alpha, beta, y.as<double>(),
+                       add ? add->as<double>() : nullptr);
 }
 
 void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, int64_t lda,
