@@ -1,0 +1,147 @@
+"""BASELINE.json's full sizes on the GPU, checked through properties that do not need the oracle
+to run at that size (it would take hours): adjoint identities and linearity of the mat-vec
+kernels, agreement of the fused one-pass sweep with the generic operator path (independent
+kernels) after a fixed number of sweeps, optimality conditions of the returned lasso solution,
+and the KKT certificate / invariants of the TV-1D prox at n = 10^8.
+
+torch is used only to generate the inputs on the device and to evaluate the checks there."""
+
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+
+# torch first: it carries its own HIP runtime, and the one that is loaded first in a process is
+# the one every later library binds to (bench.py imports in the same order)
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from epsilon_amd import ir, wire  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+M, N = 10000, 50000  # BASELINE.json configs[1]
+
+
+@pytest.fixture(scope="module")
+def lasso_instance(solve_mod):
+    import bench
+    dev = torch.device("cuda", 0)
+    At, b, lam = bench.make_instance(M, N, dev)
+    prob = bench.build_problem(At, b, lam)
+    yield dict(At=At, b=b, lam=lam, prob=prob, pb=prob.SerializeToString(),
+               data=prob.expression_data())
+    del At
+    torch.cuda.empty_cache()
+
+
+def device_map(At):
+    n, m = At.shape
+    data = {}
+    c = ir.store_device(At.data_ptr(), m, n, "f32", data, "A_full")
+    return ir.dense_matrix(constant=c, data=data)
+
+
+def test_matvec_adjoint_and_linearity_full_size(solve_mod, lasso_instance):
+    """<A x, w> = <x, A^T w> and A(x + 2y) = A x + 2 A y on the 1e4 x 5e4 matrix (K1 / K2 kernels
+    with non-temporal loads), fp32 storage against fp64 sums of the same products."""
+    solve_mod.set_option("dtype", "f32")
+    A = device_map(lasso_instance["At"])
+    rng = np.random.RandomState(0)
+    x, y, w = rng.randn(N), rng.randn(N), rng.randn(M)
+    Ax, Ay = solve_mod.linear_map_apply(A, x), solve_mod.linear_map_apply(A, y)
+    Atw = solve_mod.linear_map_apply(A, w, transpose=True)
+    lhs, rhs = float(Ax @ w), float(x @ Atw)
+    assert abs(lhs - rhs) <= 1e-4 * (np.linalg.norm(Ax) * np.linalg.norm(w))
+    Axy = solve_mod.linear_map_apply(A, x + 2 * y)
+    np.testing.assert_allclose(Axy, Ax + 2 * Ay, rtol=0, atol=2e-4 * np.abs(Axy).max())
+    # against torch's own product on the same device data
+    ref = (lasso_instance["At"].double().t() @ torch.from_numpy(x).cuda()).cpu().numpy()
+    np.testing.assert_allclose(Ax, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
+def run_sweeps(solve_mod, inst, sweeps, fused):
+    os.environ["EPSILON_HIP_FUSED"] = "1" if fused else "0"
+    try:
+        params = wire.SolverParams(max_iterations=10 ** 9, ignore_stopping_criteria=True)
+        s = solve_mod.Solver(inst["pb"], params.SerializeToString(), inst["data"])
+        s.init()
+        assert s.run(sweeps) == sweeps
+        st, x = s.result()
+        s.close()
+    finally:
+        os.environ.pop("EPSILON_HIP_FUSED", None)
+    return wire.SolverStatus.FromString(st), {k: np.frombuffer(v) for k, v in x.items()}
+
+
+def test_fused_sweep_equals_generic_path_full_size(solve_mod, lasso_instance):
+    """30 sweeps of config 2 through the fused kernel and through the generic operators
+    (GemvN / GemvT2 / ScaledZone / vector kernels): two independent implementations of the
+    same sweep."""
+    solve_mod.set_option("dtype", "f32")
+    sf, xf = run_sweeps(solve_mod, lasso_instance, 30, True)
+    sg, xg = run_sweeps(solve_mod, lasso_instance, 30, False)
+    for k in xg:
+        scale = max(np.abs(xg[k]).max(), 1e-3)
+        np.testing.assert_allclose(xf[k], xg[k], rtol=0, atol=2e-4 * scale, err_msg=k)
+    for f in ("r_norm", "s_norm"):
+        np.testing.assert_allclose(getattr(sf.residuals, f), getattr(sg.residuals, f), rtol=2e-3)
+
+
+def test_lasso_solution_optimality_full_size(solve_mod, lasso_instance):
+    """The returned point of the full-size solve: OPTIMAL by the reference's stopping rule, and
+    it satisfies the lasso optimality conditions to the accuracy that rule implies:
+    |2 A^T (A x - b)|_inf <= lam (1 + tol), correlation = -lam * sign(x) on the support."""
+    solve_mod.set_option("dtype", "f32")
+    inst = lasso_instance
+    st, x = solve_mod.solve(inst["pb"], [], wire.SolverParams(max_iterations=2000).SerializeToString(),
+                            inst["data"])
+    st = wire.SolverStatus.FromString(st)
+    assert st.state == wire.SolverStatus.OPTIMAL
+    xs = torch.from_numpy(np.frombuffer(x["var:x"]).copy()).cuda()
+    At, b, lam = inst["At"].double(), inst["b"].double(), inst["lam"]
+    r = At.t() @ xs - b
+    g = (2 * (At @ r)).cpu().numpy()
+    xh = xs.cpu().numpy()
+    assert np.abs(g).max() <= lam * 1.05
+    supp = np.abs(xh) > 1e-3 * np.abs(xh).max()
+    assert supp.sum() > 0
+    np.testing.assert_allclose(g[supp], -lam * np.sign(xh[supp]), rtol=0, atol=0.05 * lam)
+    obj = float((r @ r) + lam * xs.abs().sum())
+    assert obj < float(b @ b)  # better than x = 0
+
+
+def test_tv1d_prox_full_size(solve_mod):
+    """configs[2]: n = 10^8.  x = prox_{lam TV}(v) is certified by its KKT conditions:
+    c_k = sum_{i<=k} (x_i - v_i) satisfies |c_k| <= lam, c_n = 0 (so the mean is preserved), and
+    c_k = lam sign(x_{k+1} - x_k) wherever x jumps."""
+    import bench_tv1d
+    n = 10 ** 8
+    dev = torch.device("cuda", 0)
+    v = bench_tv1d.make_signal(n, dev).to(torch.float32)
+    x = torch.empty_like(v)
+    torch.cuda.synchronize()  # the library runs on its own stream: device inputs must be complete
+    lam = float(np.sqrt(n))
+    lev = ctypes.c_int()
+    L = solve_mod.lib()
+    solve_mod._check(L.eps_tv1d_device(ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                       ctypes.c_size_t(n), ctypes.c_int(1), ctypes.c_double(lam),
+                                       ctypes.byref(lev)))
+    assert 1 <= lev.value <= 64
+    c = torch.cumsum(x.double() - v.double(), 0)
+    tol = 2.5e-3 * lam  # x is stored in fp32 (|x| ~ 10): rounding accumulates over 1e8 partial sums
+    cmax, cend = float(c.abs().max()), abs(float(c[-1]))
+    assert cmax <= lam + tol, (cmax - lam, tol)
+    assert cend <= tol, (cend, tol)
+    d = x[1:] - x[:-1]
+    jump = d != 0
+    assert int(jump.sum()) > 100  # the signal has ~5000 steps; lam = 1e4 keeps the big ones
+    cj, dj = c[:-1][jump], d[jump].double()
+    js = float((cj - lam * torch.sign(dj)).abs().max())
+    assert js <= tol, (js, tol)
+    del c, d, jump, cj, dj, v, x
+    torch.cuda.empty_cache()
