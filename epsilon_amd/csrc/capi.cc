@@ -59,6 +59,7 @@ template <class F> int Guard(F f) {
 
 std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType dt) {
   auto dm = std::make_shared<DataMap>(dt);
+  bool device_blobs = false;
   for (size_t i = 0; i < ndata; ++i) {
     EPS_CHECK_MSG(data[i].key != nullptr, "data blob without a key");
     Blob b;
@@ -66,7 +67,14 @@ std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType d
     b.len = data[i].len;
     b.kind = data[i].kind;
     EPS_CHECK_MSG(b.kind >= 0 && b.kind <= 2, "bad blob kind " << b.kind);
+    if (b.kind != 0) device_blobs = true;
     dm->Insert(data[i].key, b);
+  }
+  // Borrowed device memory is read on this library's own non-blocking stream, which has no
+  // ordering with whatever stream produced it: wait for the device once, here.
+  if (device_blobs) {
+    Runtime::Get();
+    EPS_HIP(hipDeviceSynchronize());
   }
   return dm;
 }
@@ -513,6 +521,8 @@ int eps_tv1d_device(const void* v_dev, void* x_dev, size_t n, int kind, double l
     const DType dt = kind == EPS_BLOB_DEVICE_F32 ? F32 : F64;
     DVec v = DVec::Borrow(const_cast<void*>(v_dev), static_cast<int64_t>(n), dt);
     DVec x = DVec::Borrow(x_dev, static_cast<int64_t>(n), dt);
+    Runtime::Get();
+    EPS_HIP(hipDeviceSynchronize());  // v may have been produced on any stream of the caller
     k::Tv1d(x, v, lam);
     Runtime::Get().Sync();
     if (levels) *levels = k::Tv1dLastLevels();

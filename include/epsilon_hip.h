@@ -36,9 +36,9 @@ extern "C" {
 enum {
   EPS_BLOB_HOST = 0,       /* ptr -> host bytes, len = byte count (the reference's only form) */
   /* Device blobs are borrowed, not copied, and are read on the library's own non-blocking HIP
-   * stream: whatever produced them must have completed (stream / device synchronize) before the
-   * call that receives them, and they must stay alive and unmodified while a solver handle
-   * built from them exists. */
+   * stream.  The entry point that receives them waits for the device once (hipDeviceSynchronize),
+   * so work already enqueued by the caller is complete; they must stay alive and unmodified
+   * while a solver handle built from them exists. */
   EPS_BLOB_DEVICE_F32 = 1, /* ptr -> device memory, float,  len = element count (borrowed)   */
   EPS_BLOB_DEVICE_F64 = 2  /* ptr -> device memory, double, len = element count (borrowed)   */
 };
@@ -180,10 +180,9 @@ int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg);
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
 int eps_tv1d(const double* v, size_t n, double lam, double* x);
 
-/* The same on device-resident data (the work runs on the library's own non-blocking stream:
- * as with device blobs, the caller's writes to v must have COMPLETED before the call - e.g.
- * torch.cuda.synchronize() - there is no ordering with the caller's streams): v, x are device
- * pointers to n elements of `kind`
+/* The same on device-resident data (the work runs on the library's own non-blocking stream; the
+ * call waits for the device first, so v may come straight from the caller's streams): v, x are
+ * device pointers to n elements of `kind`
  * (EPS_BLOB_DEVICE_F32 / EPS_BLOB_DEVICE_F64); *levels (may be NULL) receives the depth of the
  * level-set recursion.  Synchronises before returning. */
 int eps_tv1d_device(const void* v_dev, void* x_dev, size_t n, int kind, double lam, int* levels);

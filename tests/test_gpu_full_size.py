@@ -124,7 +124,6 @@ def test_tv1d_prox_full_size(solve_mod):
     dev = torch.device("cuda", 0)
     v = bench_tv1d.make_signal(n, dev).to(torch.float32)
     x = torch.empty_like(v)
-    torch.cuda.synchronize()  # the library runs on its own stream: device inputs must be complete
     lam = float(np.sqrt(n))
     lev = ctypes.c_int()
     L = solve_mod.lib()
