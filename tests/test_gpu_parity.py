@@ -750,3 +750,61 @@ def test_sample_sharded_multiclass_hinge(solve_mod, tmp_path):
                                             S.residuals.epsilon_primal, S.residuals.epsilon_dual], rtol=1e-7)
         np.testing.assert_allclose(p["x1"], np.frombuffer(x["var:Theta"]), rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(t_all, np.frombuffer(x["max_entries:t"]), rtol=1e-7, atol=1e-9)
+
+
+# ---- edge cases: degenerate shapes, limits, malformed inputs -----------------------------------
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (3, 3)])
+def test_lasso_degenerate_shapes(solve_mod, dtype, shape):
+    """One row, one column, square: the elimination order, the kernels' tails and the stopping
+    rule on the smallest problems."""
+    prob, info = problems.lasso(shape[0], shape[1], seed=2)
+    sg, xg, so, xo = solve_both(solve_mod, prob, wire.SolverParams(max_iterations=200))
+    assert sg.state == so.state and sg.num_iterations == so.num_iterations
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
+    for k in xo:
+        np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
+
+
+def test_iteration_limits(solve_mod, dtype):
+    """max_iterations = 1 stops after one sweep with MAX_ITERATIONS_REACHED; zero tolerances never
+    report OPTIMAL (reference prox_admm.cc:149-168)."""
+    prob, _ = problems.lasso(20, 50, seed=1)
+    sg, xg, so, xo = solve_both(solve_mod, prob, wire.SolverParams(max_iterations=1))
+    assert sg.state == so.state == wire.SolverStatus.MAX_ITERATIONS_REACHED
+    assert sg.num_iterations == so.num_iterations
+    sg, xg, so, xo = solve_both(solve_mod, prob, wire.SolverParams(max_iterations=35, abs_tol=0, rel_tol=0))
+    assert sg.state == so.state == wire.SolverStatus.MAX_ITERATIONS_REACHED
+    assert sg.num_iterations == so.num_iterations
+
+
+def test_malformed_inputs_raise(solve_mod):
+    """Every failed check is an exception with a message, never a crash: missing data blob, blob
+    of the wrong size, argument / variable size mismatch, non-ZERO cone, rho != 1."""
+    prob, info = problems.lasso(8, 12, seed=0)
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    sb = wire.SolverParams().SerializeToString()
+    some_key = sorted(data)[0]
+    missing = {k: v for k, v in data.items() if k != some_key}
+    with pytest.raises(solve_mod.error, match="not in data map"):
+        solve_mod.solve(pb, [], sb, missing)
+    short = dict(data)
+    short[some_key] = data[some_key][:-8]
+    with pytest.raises(solve_mod.error):
+        solve_mod.solve(pb, [], sb, short)
+    with pytest.raises(solve_mod.error):
+        solve_mod.solve(pb, [], wire.SolverParams(rho=2.0).SerializeToString(), data)
+    # a linear map whose inner dimension does not match its argument
+    x = ir.variable(5, 1, "var:x")
+    bad = ir.prox(ProxFunction.SUM_SQUARE, ir.linear_map(ir.dense_matrix(np.ones((3, 5))), x))
+    bad.proto.arg[0].arg[0].size.dim[0] = 4  # the variable now has 4 entries, the map 5 columns
+    with pytest.raises(solve_mod.error):
+        solve_mod.eval_prox(bad.proto.SerializeToString(), 1.0, bad.data, {"var:x": np.zeros(4).tobytes()})
+    # v of the wrong length
+    ok = ir.prox(ProxFunction.NORM_1, ir.variable(5, 1, "var:x"))  # (a fresh, unmutated variable)
+    with pytest.raises(solve_mod.error):
+        solve_mod.eval_prox(ok.proto.SerializeToString(), 1.0, {}, {"var:x": np.zeros(4).tobytes()})
+    # the library is still usable afterwards
+    st, _ = solve_mod.solve(pb, [], sb, data)
+    assert wire.SolverStatus.FromString(st).state == wire.SolverStatus.OPTIMAL
