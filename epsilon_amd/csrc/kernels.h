@@ -67,6 +67,12 @@ void LassoFusedPass(const LassoFusedArgs& args);
 void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
           const DVec& A, int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C,
           int64_t ldc, bool lower_only = false);
+// The same for batch * outer problems (blockIdx.z = z): operands at element offsets
+// (z % batch) * s + (z / batch) * s2, results at z * sC.
+void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+                 const DVec& A, int64_t lda, int64_t sA, const DVec& B, int64_t ldb, int64_t sB,
+                 double beta, const DVec& C, int64_t ldc, int64_t sC, int64_t batch,
+                 bool lower_only = false, int64_t outer = 1, int64_t sA2 = 0, int64_t sB2 = 0);
 void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc);
 
 // dst (rows x cols, ld = rows) = alpha * op(src)
@@ -118,6 +124,10 @@ void ZoneEpigraphSums(int64_t n, const double* key, const double* w2, double lam
 // One-sided Jacobi on W (m x n, ld = m): on return W = U*Sigma (orthogonal columns) and the
 // input equals W V^T; V (n x n) is overwritten.  Returns the number of sweeps used.
 int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40);
+// The same decomposition by the block algorithm (pairs of 32-column panels: batched Gram on the
+// MFMA kernel, 64 x 64 eigenproblems on chip, batched GEMM updates); JacobiSvd switches to it
+// from 1536 columns up (measured crossover on MI355X; EPSILON_HIP_SVD=block|scalar forces one).
+int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40);
 void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma);
 // W[:, j] *= xt[j] / sigma[j]   (0 where sigma[j] == 0, as ortho_invariant.cc:44-49)
 void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt);

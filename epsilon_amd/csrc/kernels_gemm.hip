@@ -45,7 +45,13 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void GemmGenericKernel(
     int transA, int transB, int64_t M, int64_t N, int64_t K, T alpha, const T* __restrict__ A,
     int64_t lda, const T* __restrict__ B, int64_t ldb, T beta, T* C, int64_t ldc,
-    int lower_only) {
+    int lower_only, int64_t sA, int64_t sB, int64_t sC, int64_t n1, int64_t sA2, int64_t sB2) {
+  {
+    const int64_t z = blockIdx.z, z1 = z % n1, z2 = z / n1;
+    A += z1 * sA + z2 * sA2;
+    B += z1 * sB + z2 * sB2;
+    C += z * sC;
+  }
   __shared__ T As[GK][GT + 1];
   __shared__ T Bs[GK][GT + 1];
   const int64_t i0 = static_cast<int64_t>(blockIdx.x) * GT;
@@ -145,7 +151,13 @@ __device__ inline void StageTile(float (*S)[MLD], const float* __restrict__ X, i
 __global__ __launch_bounds__(kBlock) void GemmMfmaF32Kernel(
     int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
-    float beta, float* C, int64_t ldc, int lower_only) {
+    float beta, float* C, int64_t ldc, int lower_only, int64_t sA, int64_t sB, int64_t sC, int64_t n1, int64_t sA2, int64_t sB2) {
+  {
+    const int64_t z = blockIdx.z, z1 = z % n1, z2 = z / n1;
+    A += z1 * sA + z2 * sA2;
+    B += z1 * sB + z2 * sB2;
+    C += z * sC;
+  }
   __shared__ float As[MK][MLD];
   __shared__ float Bs[MK][MLD];
   const int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
@@ -293,7 +305,13 @@ template <bool CA, bool CB>
 __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* C, int64_t ldc,
-    int lower_only) {
+    int lower_only, int64_t sA, int64_t sB, int64_t sC, int64_t n1, int64_t sA2, int64_t sB2) {
+  {
+    const int64_t z = blockIdx.z, z1 = z % n1, z2 = z / n1;
+    A += z1 * sA + z2 * sA2;
+    B += z1 * sB + z2 * sB2;
+    C += z * sC;
+  }
   constexpr int LDA = StageCfg<CA>::LD, LDB = StageCfg<CB>::LD;
   // two LDS stages: slab k+1 is written while slab k is still being read, one barrier per slab
   __shared__ __attribute__((aligned(16))) float As[2][MK * LDA];
@@ -417,14 +435,27 @@ int GemmMode() {  // 0 auto, 1 generic, 2 mfma, 3 mfma without the pipelined ker
 void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
           const DVec& A, int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C,
           int64_t ldc, bool lower_only) {
+  GemmBatched(transA, transB, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1,
+              lower_only, 1, 0, 0);
+}
+
+void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+                 const DVec& A, int64_t lda, int64_t sA, const DVec& B, int64_t ldb, int64_t sB,
+                 double beta, const DVec& C, int64_t ldc, int64_t sC, int64_t batch,
+                 bool lower_only, int64_t outer, int64_t sA2, int64_t sB2) {
   EPS_CHECK(A.dt == B.dt && A.dt == C.dt);
-  if (M == 0 || N == 0) return;
+  if (M == 0 || N == 0 || batch == 0 || outer == 0) return;
+  const int64_t n1 = batch;  // inner batch count; C is indexed by the flat index
+  batch = batch * outer;
+  EPS_CHECK_MSG(batch >= 1 && batch <= 65535, "gemm: batch count out of range");
   const int64_t a_rows = transA ? K : M, a_cols = transA ? M : K;
   const int64_t b_rows = transB ? N : K, b_cols = transB ? K : N;
   EPS_CHECK_MSG(lda >= a_rows && ldb >= b_rows && ldc >= M, "gemm: bad leading dimension");
-  EPS_CHECK_MSG(K == 0 || A.n >= (a_cols - 1) * lda + a_rows, "gemm: A buffer too small");
-  EPS_CHECK_MSG(K == 0 || B.n >= (b_cols - 1) * ldb + b_rows, "gemm: B buffer too small");
-  EPS_CHECK_MSG(C.n >= (N - 1) * ldc + M, "gemm: C buffer too small");
+  EPS_CHECK_MSG(K == 0 || A.n >= (n1 - 1) * sA + (outer - 1) * sA2 + (a_cols - 1) * lda + a_rows,
+                "gemm: A buffer too small");
+  EPS_CHECK_MSG(K == 0 || B.n >= (n1 - 1) * sB + (outer - 1) * sB2 + (b_cols - 1) * ldb + b_rows,
+                "gemm: B buffer too small");
+  EPS_CHECK_MSG(C.n >= (batch - 1) * sC + (N - 1) * ldc + M, "gemm: C buffer too small");
   if (lower_only) EPS_CHECK(M == N);
   hipStream_t s = Runtime::Get().stream();
   ProfScope prof(lower_only ? "syrk" : "gemm", M * N, K);
@@ -432,8 +463,10 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
   const bool use_mfma = A.dt == F32 && mode != 1 &&
                         (mode >= 2 || (M >= 64 && N >= 64 && K >= 32));
   if (use_mfma) {
-    dim3 grid(static_cast<unsigned>((M + MT - 1) / MT), static_cast<unsigned>((N + MT - 1) / MT));
-    const bool aligned = lda % 4 == 0 && ldb % 4 == 0 &&
+    dim3 grid(static_cast<unsigned>((M + MT - 1) / MT), static_cast<unsigned>((N + MT - 1) / MT),
+              static_cast<unsigned>(batch));
+    const bool aligned = lda % 4 == 0 && ldb % 4 == 0 && sA % 4 == 0 && sB % 4 == 0 &&
+                         sA2 % 4 == 0 && sB2 % 4 == 0 &&
                          reinterpret_cast<uintptr_t>(A.data()) % 16 == 0 &&
                          reinterpret_cast<uintptr_t>(B.data()) % 16 == 0;
     if (aligned && mode != 3) {
@@ -441,7 +474,7 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
       const int lo = lower_only ? 1 : 0;
 #define EPS_PIPE(CA, CB)                                                                       \
   hipLaunchKernelGGL((GemmMfmaF32PipeKernel<CA, CB>), grid, dim3(kBlock), 0, s, M, N, K, al,    \
-                     A.as<float>(), lda, B.as<float>(), ldb, be, C.as<float>(), ldc, lo)
+                     A.as<float>(), lda, B.as<float>(), ldb, be, C.as<float>(), ldc, lo, sA, sB, sC, n1, sA2, sB2)
       if (!transA && transB) EPS_PIPE(true, true);
       else if (!transA && !transB) EPS_PIPE(true, false);
       else if (transA && transB) EPS_PIPE(false, true);
@@ -452,19 +485,20 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
     hipLaunchKernelGGL(GemmMfmaF32Kernel, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
                        transB ? 1 : 0, M, N, K, static_cast<float>(alpha), A.as<float>(), lda,
                        B.as<float>(), ldb, static_cast<float>(beta), C.as<float>(), ldc,
-                       lower_only ? 1 : 0);
+                       lower_only ? 1 : 0, sA, sB, sC, n1, sA2, sB2);
     return;
   }
-  dim3 grid(static_cast<unsigned>((M + GT - 1) / GT), static_cast<unsigned>((N + GT - 1) / GT));
+  dim3 grid(static_cast<unsigned>((M + GT - 1) / GT), static_cast<unsigned>((N + GT - 1) / GT),
+            static_cast<unsigned>(batch));
   if (A.dt == F32) {
     hipLaunchKernelGGL(GemmGenericKernel<float>, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
                        transB ? 1 : 0, M, N, K, static_cast<float>(alpha), A.as<float>(), lda,
                        B.as<float>(), ldb, static_cast<float>(beta), C.as<float>(), ldc,
-                       lower_only ? 1 : 0);
+                       lower_only ? 1 : 0, sA, sB, sC, n1, sA2, sB2);
   } else {
     hipLaunchKernelGGL(GemmGenericKernel<double>, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
                        transB ? 1 : 0, M, N, K, alpha, A.as<double>(), lda, B.as<double>(), ldb,
-                       beta, C.as<double>(), ldc, lower_only ? 1 : 0);
+                       beta, C.as<double>(), ldc, lower_only ? 1 : 0, sA, sB, sC, n1, sA2, sB2);
   }
 }
 

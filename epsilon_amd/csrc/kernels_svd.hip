@@ -9,6 +9,11 @@
 // to the column pair of W and of V).  After convergence W = U Sigma and Y = W V^T.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #include "kernels.h"
 
 namespace eps {
@@ -139,11 +144,262 @@ template <class T> __global__ void EyeKernel(T* V, int64_t n) {
   if (idx < n * n) V[idx] = (idx % n == idx / n) ? T(1) : T(0);
 }
 
+// ---- block one-sided Jacobi ------------------------------------------------------------------------
+// For more than a few hundred columns the scalar algorithm above streams the whole matrix once
+// per rotation step (n - 1 steps per sweep).  The block form works on pairs of 32-column panels:
+//   G_k = P_k^T P_k           (64 x 64 Gram of the panel pair, batched GEMM on the MFMA kernel)
+//   G_k = J_k D J_k^T         (on chip: one workgroup per pair, one-sided Jacobi in LDS)
+//   P_k <- P_k J_k, V_k <- V_k J_k   (batched GEMMs)
+// so a sweep is nb - 1 steps of GEMMs instead of n - 1 streaming passes.  Panels are kept
+// physically adjacent (pair k = column blocks 2k, 2k+1) and moved by the round-robin permutation
+// after every step.
+
+constexpr int kJB = 32;         // panel width
+constexpr int kJN = 2 * kJB;    // order of the pair problems
+constexpr int kJLd = kJN + 1;   // LDS row stride
+
+// One workgroup per pair: G (sum of `nsplit` partial Grams) -> eigenvectors J (kJN x kJN).
+// Also folds max_{i != j} |G_ij| / sqrt(G_ii G_jj) into *offmax (float bits, atomicMax).
+template <class T>
+__global__ __launch_bounds__(kBlock) void PairEigKernel(const T* __restrict__ G, int nsplit,
+                                                        int64_t split_stride, T* __restrict__ J,
+                                                        int inner_sweeps, double tol,
+                                                        unsigned int* offmax) {
+  __shared__ T A[kJN * kJLd];  // column-major: A[c * kJLd + r]
+  __shared__ T E[kJN * kJLd];
+  __shared__ float wmax[kBlock / 64];
+  const int t = threadIdx.x;
+  const T* g = G + static_cast<int64_t>(blockIdx.x) * kJN * kJN;
+  for (int idx = t; idx < kJN * kJN; idx += kBlock) {
+    const int r = idx % kJN, c = idx / kJN;
+    T v = T(0);
+    for (int sp = 0; sp < nsplit; ++sp) v += g[sp * split_stride + idx];
+    A[c * kJLd + r] = v;
+    E[c * kJLd + r] = (r == c) ? T(1) : T(0);
+  }
+  __syncthreads();
+  // symmetrise (the partial sums of the two triangles differ in rounding) and measure
+  float mx = 0.0f;
+  for (int idx = t; idx < kJN * kJN; idx += kBlock) {
+    const int r = idx % kJN, c = idx / kJN;
+    if (r > c) {
+      const double v = 0.5 * (static_cast<double>(A[c * kJLd + r]) + static_cast<double>(A[r * kJLd + c]));
+      const double d = static_cast<double>(A[r * kJLd + r]) * static_cast<double>(A[c * kJLd + c]);
+      if (d > 0) mx = fmaxf(mx, static_cast<float>(fabs(v) / sqrt(d)));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((t & 63) == 0) wmax[t >> 6] = mx;
+  __syncthreads();
+  if (t == 0) {
+    float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    atomicMax(offmax, __float_as_uint(m4));
+  }
+  // one-sided Jacobi on the columns of A; kJN / 2 = 32 pairs per step, 8 lanes per pair
+  constexpr int kTpp = kBlock / (kJN / 2);
+  const int pair = t / kTpp, sub = t % kTpp;
+  for (int sw = 0; sw < inner_sweeps; ++sw) {
+    for (int step = 0; step < kJN - 1; ++step) {
+      int64_t p, q;
+      TournamentPair(kJN, step, pair, &p, &q);
+      T* ap = A + p * kJLd;
+      T* aq = A + q * kJLd;
+      // rotations in the storage precision (these are 64 x 64 problems whose result only has to
+      // reduce the off-diagonal mass: the outer iteration corrects what an inner one leaves)
+      T a = 0, b = 0, gm = 0;
+      for (int r = sub; r < kJN; r += kTpp) {
+        const T x = ap[r], y = aq[r];
+        a += x * x;
+        b += y * y;
+        gm += x * y;
+      }
+#pragma unroll
+      for (int off = kTpp / 2; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+        gm += __shfl_xor(gm, off, 64);
+      }
+      T c = 1, s = 0;
+      if (fabs(gm) > static_cast<T>(tol) * sqrt(a * b) && gm != T(0)) {
+        const T zeta = (b - a) / (T(2) * gm);
+        const T tt = (zeta >= 0 ? T(1) : T(-1)) / (fabs(zeta) + sqrt(T(1) + zeta * zeta));
+        c = T(1) / sqrt(T(1) + tt * tt);
+        s = c * tt;
+      }
+      if (s != T(0)) {
+        T* ep = E + p * kJLd;
+        T* eq = E + q * kJLd;
+        for (int r = sub; r < kJN; r += kTpp) {
+          const T x = ap[r], y = aq[r];
+          ap[r] = c * x - s * y;
+          aq[r] = s * x + c * y;
+          const T u = ep[r], w = eq[r];
+          ep[r] = c * u - s * w;
+          eq[r] = s * u + c * w;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  T* j = J + static_cast<int64_t>(blockIdx.x) * kJN * kJN;
+  for (int idx = t; idx < kJN * kJN; idx += kBlock) {
+    const int r = idx % kJN, c = idx / kJN;
+    j[idx] = E[c * kJLd + r];
+  }
+}
+
+// dst[:, dst_block[b]] = src[:, b] for column blocks of kJB columns (rows x nblocks*kJB)
+template <class T>
+__global__ __launch_bounds__(kBlock) void PermuteBlocksKernel(T* __restrict__ dst,
+                                                              const T* __restrict__ src,
+                                                              int64_t rows,
+                                                              const int32_t* __restrict__ dst_block) {
+  const int64_t b = blockIdx.y;
+  const int64_t per = rows * kJB;
+  const T* s = src + b * per;
+  T* d = dst + static_cast<int64_t>(dst_block[b]) * per;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x; i < per;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    d[i] = s[i];
+}
+
+// dst (rows_out x ncols, ld rows_out) column j = src (ld lds) column col[j], first rows_out rows
+template <class T>
+__global__ __launch_bounds__(kBlock) void GatherColsKernel(T* __restrict__ dst, int64_t rows_out,
+                                                           const T* __restrict__ src, int64_t lds,
+                                                           const int32_t* __restrict__ col) {
+  const int64_t j = blockIdx.x;
+  const T* s = src + static_cast<int64_t>(col[j]) * lds;
+  T* d = dst + j * rows_out;
+  for (int64_t i = threadIdx.x; i < rows_out; i += kBlock) d[i] = s[i];
+}
+
+template <class T>
+int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  const DType dt = W.dt;
+  int64_t nb = (n + kJB - 1) / kJB;
+  if (nb & 1) ++nb;
+  const int64_t h = nb / 2, npad = nb * kJB;
+  const double tol = dt == F32 ? 1e-7 : 1e-15;       // rotation threshold
+  const double done_tol = dt == F32 ? 3e-6 : 1e-13;  // max |cos| between columns at convergence
+  // split-K for the Gram products so that more than h workgroups run; rows are padded with
+  // zeros to nsplit equal chunks of a multiple of 32 rows (16-byte aligned slices)
+  int64_t nsplit = 1;
+  while (nsplit < 8 && h * nsplit < 512 && m / (nsplit * 2) >= 256) nsplit *= 2;
+  const int64_t kchunk = ((m + nsplit - 1) / nsplit + 31) / 32 * 32;
+  const int64_t mp = nsplit * kchunk;
+  // padded working copies
+  DVec Wp = DVec::Zeros(mp * npad, dt), Wt = DVec::Empty(mp * npad, dt);
+  DVec Vp = DVec::Zeros(npad * npad, dt), Vt = DVec::Empty(npad * npad, dt);
+  EPS_HIP(hipMemcpy2DAsync(Wp.data(), mp * sizeof(T), W.data(), m * sizeof(T), m * sizeof(T), n,
+                           hipMemcpyDeviceToDevice, s));
+  AddDiag(Vp, npad, npad, 1.0, nullptr);
+  DVec G = DVec::Empty(nsplit * h * kJN * kJN, dt), J = DVec::Empty(h * kJN * kJN, dt);
+  // round-robin: position layout [top_0 bot_0 top_1 bot_1 ...]; after a step
+  //   new_top[0] = top[0], new_top[1] = bot[0], new_top[k] = top[k-1] (k >= 2),
+  //   new_bot[k] = bot[k+1] (k < h-1), new_bot[h-1] = top[h-1]
+  std::vector<int32_t> dst(nb);
+  if (h == 1) {
+    dst[0] = 0;
+    dst[1] = 1;
+  } else {
+    dst[0] = 0;                                           // top[0] stays
+    dst[1] = 2 * 1;                                       // bot[0] -> top[1]
+    for (int64_t k = 1; k < h - 1; ++k) dst[2 * k] = static_cast<int32_t>(2 * (k + 1));  // top[k] -> top[k+1]
+    dst[2 * (h - 1)] = static_cast<int32_t>(2 * (h - 1) + 1);                            // top[h-1] -> bot[h-1]
+    for (int64_t k = 1; k < h; ++k) dst[2 * k + 1] = static_cast<int32_t>(2 * (k - 1) + 1);  // bot[k] -> bot[k-1]
+  }
+  auto dst_buf = rt.Alloc(nb * sizeof(int32_t));
+  EPS_HIP(hipMemcpyAsync(dst_buf->p, dst.data(), nb * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  EPS_HIP(hipStreamSynchronize(s));
+  const int32_t* dst_dev = static_cast<const int32_t*>(dst_buf->p);
+  auto flag_buf = rt.Alloc(sizeof(unsigned int));
+  unsigned int* offmax = static_cast<unsigned int*>(flag_buf->p);
+  std::vector<int32_t> block_at(nb);  // original block id at each position
+  for (int64_t i = 0; i < nb; ++i) block_at[i] = static_cast<int32_t>(i);
+  const int64_t steps = nb - 1;
+  static const char* inner_env = std::getenv("EPSILON_HIP_SVD_INNER");  // tuning knob
+  const int inner = inner_env && std::atoi(inner_env) > 0 ? std::atoi(inner_env) : 2;
+  int sweeps = 0;
+  float prev_mx = 1e30f;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    EPS_HIP(hipMemsetAsync(offmax, 0, sizeof(unsigned int), s));
+    for (int64_t step = 0; step < steps; ++step) {
+      // partial Grams in one launch: batch index = split * h + pair, split sp covers rows
+      // [sp * kchunk, (sp + 1) * kchunk) of the panels (the last chunk is padded with zero rows)
+      GemmBatched(true, false, kJN, kJN, kchunk, 1.0, Wp, mp, kJN * mp, Wp, mp, kJN * mp, 0.0, G,
+                  kJN, kJN * kJN, h, false, nsplit, kchunk, kchunk);
+      hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
+                         G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
+                         offmax);
+      GemmBatched(false, false, mp, kJN, kJN, 1.0, Wp, mp, kJN * mp, J, kJN, kJN * kJN, 0.0, Wt,
+                  mp, kJN * mp, h);
+      GemmBatched(false, false, npad, kJN, kJN, 1.0, Vp, npad, kJN * npad, J, kJN, kJN * kJN, 0.0,
+                  Vt, npad, kJN * npad, h);
+      const dim3 gw(static_cast<unsigned>(std::min<int64_t>(64, (mp * kJB + kBlock - 1) / kBlock)),
+                    static_cast<unsigned>(nb));
+      hipLaunchKernelGGL(PermuteBlocksKernel<T>, gw, dim3(kBlock), 0, s, Wp.as<T>(), Wt.as<T>(), mp,
+                         dst_dev);
+      const dim3 gv(static_cast<unsigned>(std::min<int64_t>(64, (npad * kJB + kBlock - 1) / kBlock)),
+                    static_cast<unsigned>(nb));
+      hipLaunchKernelGGL(PermuteBlocksKernel<T>, gv, dim3(kBlock), 0, s, Vp.as<T>(), Vt.as<T>(),
+                         npad, dst_dev);
+      std::vector<int32_t> next(nb);
+      for (int64_t i = 0; i < nb; ++i) next[dst[i]] = block_at[i];
+      block_at.swap(next);
+    }
+    unsigned int bits = 0;
+    EPS_HIP(hipMemcpyAsync(&bits, offmax, sizeof(bits), hipMemcpyDeviceToHost, s));
+    EPS_HIP(hipStreamSynchronize(s));
+    float mx;
+    std::memcpy(&mx, &bits, sizeof(mx));
+    // converged, or stagnating at the noise floor of the Gram products (fp32: ~1e-5)
+    if (mx <= done_tol || (sweeps >= 3 && mx < 1e-3f && mx >= 0.5f * prev_mx)) {
+      ++sweeps;
+      break;
+    }
+    prev_mx = mx;
+  }
+  // the n real columns, wherever they ended up (padding columns are exactly zero and never mix)
+  std::vector<int32_t> cols;
+  cols.reserve(n);
+  for (int64_t pos = 0; pos < nb; ++pos)
+    for (int64_t c = 0; c < kJB; ++c)
+      if (static_cast<int64_t>(block_at[pos]) * kJB + c < n) cols.push_back(static_cast<int32_t>(pos * kJB + c));
+  EPS_CHECK(static_cast<int64_t>(cols.size()) == n);
+  auto col_buf = rt.Alloc(n * sizeof(int32_t));
+  EPS_HIP(hipMemcpyAsync(col_buf->p, cols.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  EPS_HIP(hipStreamSynchronize(s));
+  const int32_t* col_dev = static_cast<const int32_t*>(col_buf->p);
+  hipLaunchKernelGGL(GatherColsKernel<T>, dim3(static_cast<unsigned>(n)), dim3(kBlock), 0, s,
+                     W.as<T>(), m, Wp.as<T>(), mp, col_dev);
+  hipLaunchKernelGGL(GatherColsKernel<T>, dim3(static_cast<unsigned>(n)), dim3(kBlock), 0, s,
+                     V.as<T>(), n, Vp.as<T>(), npad, col_dev);
+  EPS_HIP(hipGetLastError());
+  return sweeps;
+}
+
 }  // namespace
+
+int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps) {
+  EPS_CHECK(W.n >= m * n && V.n >= n * n && W.dt == V.dt);
+  if (m == 0 || n == 0) return 0;
+  ProfScope prof("block_jacobi_svd", m, n);
+  return W.dt == F32 ? BlockJacobiImpl<float>(W, m, n, V, max_sweeps)
+                     : BlockJacobiImpl<double>(W, m, n, V, max_sweeps);
+}
 
 int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps) {
   EPS_CHECK(W.n >= m * n && V.n >= n * n && W.dt == V.dt);
   if (m == 0 || n == 0) return 0;
+  {
+    const char* env = std::getenv("EPSILON_HIP_SVD");  // "scalar" | "block" (read per call)
+    const bool force_scalar = env && env[0] == 's', force_block = env && env[0] == 'b';
+    if (!force_scalar && (force_block || n >= 1536)) return BlockJacobiSvd(W, m, n, V, max_sweeps);
+  }
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   ProfScope prof("jacobi_svd", m, n);

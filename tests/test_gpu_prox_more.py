@@ -363,3 +363,61 @@ def test_matrix_epigraphs(solve_mod, dtype, name):  # prox_test.py:221,226,229
         V = sym(rng, n) if name != "norm_nuclear" else rng.randn(n, n)
         run(solve_mod, e, 1.0, {"var:X": V.reshape(-1, order="F"), "var:t": [rng.randn()]},
             tol_for(dtype, f64=1e-7, f32=3e-3))
+
+
+@pytest.fixture
+def block_svd():
+    """The block Jacobi takes over from 1536 columns; EPSILON_HIP_SVD=block forces it for the
+    small shapes of these tests (the library reads the variable on every call)."""
+    import os
+    old = os.environ.get("EPSILON_HIP_SVD")
+    os.environ["EPSILON_HIP_SVD"] = "block"
+    yield
+    if old is None:
+        os.environ.pop("EPSILON_HIP_SVD", None)
+    else:
+        os.environ["EPSILON_HIP_SVD"] = old
+
+
+@pytest.mark.parametrize("shape", [(300, 250), (250, 400), (200, 200), (520, 193)])
+def test_nuclear_norm_block_jacobi(solve_mod, dtype, shape, block_svd):
+    """The block Jacobi SVD (batched Gram on the MFMA kernel, 64 x 64 eigenproblems on chip):
+    nuclear-norm prox of tall, wide and square matrices against the singular value thresholding
+    of numpy's SVD."""
+    rng = np.random.RandomState(shape[0])
+    m, n = shape
+    r = 12
+    V = rng.randn(m, r) @ rng.randn(r, n) + 0.1 * rng.randn(m, n)  # low rank + noise, as in RPCA
+    lam = 3.0
+    X = ir.variable(m, n, "var:X")
+    e = ir.prox(ProxFunction.NORM_NUCLEAR, X)
+    fb = e.proto.SerializeToString()
+    got = solve_mod.eval_prox(fb, lam, e.data, {"var:X": V.reshape(-1, order="F").tobytes()})
+    G = np.frombuffer(got["var:X"]).reshape((m, n), order="F")
+    U, sv, Vt = np.linalg.svd(V, full_matrices=False)
+    want = (U * np.maximum(sv - lam, 0)) @ Vt
+    tol = dict(rtol=0, atol=1e-8 * sv[0]) if dtype == "f64" else dict(rtol=0, atol=3e-4 * sv[0])
+    np.testing.assert_allclose(G, want, **tol)
+
+
+def test_symmetric_functions_block_jacobi(solve_mod, dtype, block_svd):
+    """SEMIDEFINITE and NEG_LOG_DET at n = 256 (block path through the shifted SVD)."""
+    rng = np.random.RandomState(7)
+    n = 256
+    A = rng.randn(n, n)
+    S = (A + A.T) / 2
+    X = ir.variable(n, n, "var:X")
+    got = solve_mod.eval_prox(ir.prox(ProxFunction.SEMIDEFINITE, X).proto.SerializeToString(), 1.0, {},
+                              {"var:X": S.reshape(-1, order="F").tobytes()})
+    G = np.frombuffer(got["var:X"]).reshape((n, n), order="F")
+    d, Q = np.linalg.eigh(S)
+    want = (Q * np.maximum(d, 0)) @ Q.T
+    scale = np.abs(d).max()
+    np.testing.assert_allclose(G, want, rtol=0, atol=(1e-8 if dtype == "f64" else 2e-3) * scale)
+    lam = 0.7
+    got = solve_mod.eval_prox(ir.prox(ProxFunction.NEG_LOG_DET, X).proto.SerializeToString(), lam, {},
+                              {"var:X": S.reshape(-1, order="F").tobytes()})
+    G = np.frombuffer(got["var:X"]).reshape((n, n), order="F")
+    dd = (d + np.sqrt(d * d + 4 * lam)) / 2
+    want = (Q * dd) @ Q.T
+    np.testing.assert_allclose(G, want, rtol=0, atol=(1e-8 if dtype == "f64" else 2e-3) * scale)
