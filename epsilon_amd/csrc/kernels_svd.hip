@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -164,7 +165,7 @@ template <class T>
 __global__ __launch_bounds__(kBlock) void PairEigKernel(const T* __restrict__ G, int nsplit,
                                                         int64_t split_stride, T* __restrict__ J,
                                                         int inner_sweeps, double tol,
-                                                        unsigned int* offmax) {
+                                                        double skip_below, unsigned int* offmax) {
   __shared__ T A[kJN * kJLd];  // column-major: A[c * kJLd + r]
   __shared__ T E[kJN * kJLd];
   __shared__ float wmax[kBlock / 64];
@@ -192,9 +193,13 @@ __global__ __launch_bounds__(kBlock) void PairEigKernel(const T* __restrict__ G,
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   if ((t & 63) == 0) wmax[t >> 6] = mx;
   __syncthreads();
-  if (t == 0) {
-    float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    atomicMax(offmax, __float_as_uint(m4));
+  const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  if (t == 0) atomicMax(offmax, __float_as_uint(m4));
+  if (m4 <= static_cast<float>(skip_below)) {
+    // this pair of panels is already orthogonal to working accuracy: J = I, no sweeps
+    T* jj = J + static_cast<int64_t>(blockIdx.x) * kJN * kJN;
+    for (int idx = t; idx < kJN * kJN; idx += kBlock) jj[idx] = (idx % kJN == idx / kJN) ? T(1) : T(0);
+    return;
   }
   // one-sided Jacobi on the columns of A; kJN / 2 = 32 pairs per step, 8 lanes per pair
   constexpr int kTpp = kBlock / (kJN / 2);
@@ -334,7 +339,7 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
                   kJN, kJN * kJN, h, false, nsplit, kchunk, kchunk);
       hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
                          G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
-                         offmax);
+                         done_tol, offmax);
       GemmBatched(false, false, mp, kJN, kJN, 1.0, Wp, mp, kJN * mp, J, kJN, kJN * kJN, 0.0, Wt,
                   mp, kJN * mp, h);
       GemmBatched(false, false, npad, kJN, kJN, 1.0, Vp, npad, kJN * npad, J, kJN, kJN * kJN, 0.0,
@@ -356,6 +361,8 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
     EPS_HIP(hipStreamSynchronize(s));
     float mx;
     std::memcpy(&mx, &bits, sizeof(mx));
+    if (std::getenv("EPSILON_HIP_SVD_VERBOSE"))
+      std::fprintf(stderr, "block jacobi sweep %d: max |cos| %.3e\n", sweeps, static_cast<double>(mx));
     // converged, or stagnating at the noise floor of the Gram products (fp32: ~1e-5)
     if (mx <= done_tol || (sweeps >= 3 && mx < 1e-3f && mx >= 0.5f * prev_mx)) {
       ++sweeps;
