@@ -143,6 +143,11 @@ def main():
         from epsilon_amd import dist as edist
         cols = edist.column_range(n, rank, world)
         edist.init_comm(rank, world, backend=args.comm)
+        # RCCL connects lazily on the first collective: do that (and a 100 MB one, the size class
+        # of the Gram all-reduce) before anything is timed
+        _solve.comm_warmup(1 << 16)
+        if args.comm == "rccl":
+            _solve.comm_warmup(25 * (1 << 20))
     else:
         cols = None
     At, b, lam = make_instance(m, n, device, cols=cols)

@@ -236,6 +236,12 @@ def comm_init_callback(rank, world, fn):
     _check(lib().eps_comm_init_callback(ctypes.c_int(rank), ctypes.c_int(world), cb, None))
 
 
+def comm_warmup(count=1 << 20):
+    """Collective: one checked all-reduce + all-gather of `count` floats (barrier + RCCL first-use
+    setup)."""
+    _check(lib().eps_comm_warmup(ctypes.c_size_t(count)))
+
+
 def comm_shutdown():
     _check(lib().eps_comm_shutdown())
     del _comm_keep[:]

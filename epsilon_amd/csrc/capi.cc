@@ -307,6 +307,25 @@ int eps_comm_init_callback(int rank, int world, eps_allreduce_fn fn, void* ctx) 
   });
 }
 
+int eps_comm_warmup(size_t count) {
+  return Guard([&] {
+    Runtime& rt = Runtime::Get();
+    EPS_CHECK_MSG(rt.comm() != nullptr, "eps_comm_warmup: no communicator");
+    // one all-reduce and one all-gather of `count` floats: RCCL sets up its rings / buffers on
+    // the first collective of each kind, which should not land inside a timed solver Init
+    const int64_t n = static_cast<int64_t>(count < 1 ? 1 : count);
+    DVec a = DVec::Full(n, 1.0, F32);
+    rt.comm()->AllReduceSum(a);
+    DVec g = DVec::Zeros(n * rt.comm()->size(), F32);
+    rt.comm()->AllGather(a.data(), g.data(), static_cast<size_t>(n), F32);
+    rt.Sync();
+    std::vector<double> h = a.Slice(0, 1).ToHost();
+    EPS_CHECK_MSG(h[0] == static_cast<double>(rt.comm()->size()),
+                  "eps_comm_warmup: all-reduce of ones gave " << h[0] << " on "
+                                                              << rt.comm()->size() << " ranks");
+  });
+}
+
 int eps_comm_shutdown(void) {
   return Guard([&] {
     Runtime& rt = Runtime::Get();

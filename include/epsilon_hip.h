@@ -136,6 +136,9 @@ int eps_comm_init_rccl(int rank, int world, const void* id128);
  * ranks on one GPU or over gloo. */
 typedef void (*eps_allreduce_fn)(void* host_buf, size_t count, int dtype, void* ctx);
 int eps_comm_init_callback(int rank, int world, eps_allreduce_fn fn, void* ctx);
+/* One all-reduce + one all-gather of `count` floats over the communicator, checked (sum of ones
+ * == world size): a barrier that also takes RCCL's first-use setup out of a timed Init. */
+int eps_comm_warmup(size_t count);
 int eps_comm_shutdown(void);
 /* Replace the set of sharded block keys (variable ids and "constraint:<i>" rows). */
 int eps_shard_keys(const char* const* keys, size_t nkeys);

@@ -46,6 +46,7 @@ def main():
         c_vec = -(X.T.dot(Y)).reshape(1, -1, order="F")
         _solve.set_option("dtype", os.environ.get("EPS_TEST_DTYPE", "f64"))
         edist.init_comm(rank, world, backend="host")
+        _solve.comm_warmup(64)  # checked all-reduce + all-gather across the ranks
         prob, _ = problems.multiclass_hinge(X[lo:hi], Y[lo:hi], 0.1, c_vec=c_vec)
         _solve.shard_keys(["max_entries:t", "non_negative:y", "constraint:0"])
         params = wire.SolverParams(max_iterations=max_iter)

@@ -20,6 +20,7 @@ from oracle import epsilon_oracle as orc  # noqa: E402
 dist.init_process_group("gloo", rank=0, world_size=1)
 _solve.set_option("dtype", "f64")
 edist.init_comm(0, 1, backend="rccl")
+_solve.comm_warmup(1 << 12)  # checked all-reduce + all-gather through RCCL
 prob, info = problems.lasso(40, 101, seed=3)
 edist.mark_sharded(None, prob)
 pb, sb = prob.SerializeToString(), wire.SolverParams().SerializeToString()
