@@ -170,15 +170,34 @@ def main():
     # ---- wall-clock-to-eps at the reference defaults (benchmark.py:130-136: max_iterations 50000)
     if not args.no_time_to_eps:
         s = new_solver(wire.SolverParams(max_iterations=50000))
+        # two HIP-event brackets inside Init: the Gram SYRK (the MFMA contraction of the
+        # least-squares prox) and the explicit inverse
+        _solve.set_option("profile_filter", "syrk:%d" % (m * m) + ",spd_inverse")
+        _solve.profile_enable(True)
+        _solve.profile_reset()
         barrier()
         t0 = time.time()
         s.init()
         barrier()
         t_init = time.time() - t0
+        init_prof = _solve.profile_dump()
+        _solve.profile_enable(False)
         s.run(-1)
         barrier()
         t_total = time.time() - t0
         st = wire.SolverStatus.FromString(s.result()[0])
+        gram = init_prof.get("syrk:%dx%d" % (m * m, At.shape[0]))
+        if gram and gram[0]:
+            gram_ms = gram[1] / gram[0]
+            flops = float(m) * (m + 1) * At.shape[0]  # lower triangle incl. diagonal, 2 flops / MAC
+            out["init_breakdown"] = {
+                "gram_syrk_ms": gram_ms,
+                "gram": {"bound": "mfma", "kernel": "GemmMfmaF32PipeKernel<true,true> (SYRK A A^T, lower tiles)",
+                         "achieved": flops / (gram_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": flops / (gram_ms * 1e-3) / 1e12 / 157.3,
+                         "gemm_equivalent_TFLOPs": 2.0 * m * m * At.shape[0] / (gram_ms * 1e-3) / 1e12},
+                "explicit_inverse_ms": (init_prof.get("spd_inverse:%d" % m, (0, 0.0))[1]),
+            }
         out.update(init_s=t_init, time_to_eps_s=t_total,
                    iters_to_eps=st.num_iterations + 1,
                    state_at_eps=["NOT_STARTED", "INITIALIZING", "RUNNING", "OPTIMAL",

@@ -178,11 +178,13 @@ bool Runtime::ProfWanted(const char* name) const {
 
 ProfScope::ProfScope(const char* name, int64_t a, int64_t b) {
   Runtime& rt = Runtime::Get();
-  on = rt.profiling() && rt.ProfWanted(name);
-  if (!on) return;
+  on = false;
+  if (!rt.profiling()) return;
   std::string tag = name;
   if (a >= 0) tag += ":" + std::to_string(a);
   if (b >= 0) tag += "x" + std::to_string(b);
+  on = rt.ProfWanted(tag.c_str());  // filter prefixes are matched against the full tag
+  if (!on) return;
   index = rt.ProfBegin(tag);
 }
 
