@@ -17,6 +17,14 @@ from oracle import epsilon_oracle as orc
 from oracle.epsilon_oracle import LM, BlockCholesky, BlockMatrix, BlockVector
 
 
+import json as _json
+import os as _os
+
+GOLDEN = _json.load(open(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden",
+                                       "reference_known_answers.json")))
+
+
+
 def rnd(rng, *shape):
     return rng.uniform(-1, 1, size=shape)  # Eigen::Random is uniform on [-1, 1]
 
@@ -112,8 +120,9 @@ def test_compute_fill_exact_values():  # block_cholesky_test.cc:60-74: 4 and 25
     A.set("one", "two", LM.dense(A0))
     A.set("two", "one", LM.dense(A0.T))
     A.set("two", "two", LM.identity(2))
-    assert orc.compute_fill(A, "one") == 4
-    assert orc.compute_fill(A, "two") == 25
+    want = GOLDEN["compute_fill"]["fill_when_eliminating"]  # 4 and 25
+    assert orc.compute_fill(A, "one") == want["one"]
+    assert orc.compute_fill(A, "two") == want["two"]
 
 
 def test_block_cholesky_vs_dense_solve():  # block_cholesky_test.cc:76-104

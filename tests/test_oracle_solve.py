@@ -48,9 +48,13 @@ def test_stopping_iterations_match_survey_probe():
     """SURVEY.md 3.3 / BASELINE.md section 2: the compiled reference stops lasso 200x500 at
     iteration 30 (PROX_ADMM) and 40 (TWO_BLOCK); the restatement does the same on an
     instance of the same distribution."""
-    prob, _ = problems.lasso(200, 500, seed=0)
-    assert solve(prob, solver=0)[0].num_iterations == 30
-    assert solve(prob, solver=1)[0].num_iterations == 40
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                    "reference_known_answers.json")))["lasso_stopping_iteration"]
+    prob, _ = problems.lasso(g["m"], g["n"], seed=0)
+    assert solve(prob, solver=0)[0].num_iterations == g["PROX_ADMM"]
+    assert solve(prob, solver=1)[0].num_iterations == g["PROX_ADMM_TWO_BLOCK"]
 
 
 def test_c_oracle_equals_generic_oracle():
