@@ -331,7 +331,9 @@ class ScaledZoneEpigraph final : public VectorProx {
   void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
     const DVec& v = input.value_vec(0);
     const DVec& sv = input.value_vec(1);
-    if (input.prox_function().has_axis) {  // one projection per row / column, solved on chip
+    // one projection per row / column - or one short vector - is solved on chip by one launch
+    // with no host round trip; a long single vector takes the device-wide reductions below
+    if (input.prox_function().has_axis || v.n <= 65536) {
       DVec x = DVec::Empty(v.n, v.dt), t = DVec::Empty(sv.n, sv.dt);
       k::SegZoneEpigraph(x, t, v, sv, alpha_.value, beta_.value,
                          alpha_.is_vec ? &alpha_.vec : nullptr, beta_.is_vec ? &beta_.vec : nullptr,

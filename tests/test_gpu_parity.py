@@ -730,6 +730,20 @@ def test_epigraph_projections(solve_mod, dtype, kind):
         run_prox(solve_mod, expr, 1.0, {"var:x": v, "var:t": np.array([s])}, tol)
 
 
+@pytest.mark.parametrize("kind", ["norm_1", "hinge"])
+def test_epigraph_projection_long_vector(solve_mod, dtype, kind):
+    """Above 65536 entries the scaled-zone epigraph runs device-wide reductions with the active-set
+    iteration on the host (shorter vectors are solved on chip by one launch)."""
+    n = 200000
+    rng = np.random.RandomState(5)
+    x, t = ir.variable(n, 1, "var:x"), ir.variable(1, 1, "var:t")
+    typ = ProxFunction.NORM_1 if kind == "norm_1" else ProxFunction.SUM_HINGE
+    v, s = rng.randn(n), 0.05 * n
+    expr = ir.prox(typ, x, t, epigraph=True)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=3e-4, atol=3e-4)
+    run_prox(solve_mod, expr, 1.0, {"var:x": v, "var:t": np.array([s])}, tol)
+
+
 def test_sample_sharded_multiclass_hinge(solve_mod, tmp_path):
     """BASELINE.json configs[3] shape: multiclass hinge with the SAMPLES sharded over 2 ranks
     (t, y and the big constraint row are sharded; Theta is replicated).  The contraction
