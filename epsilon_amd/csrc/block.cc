@@ -512,7 +512,19 @@ void BlockCholesky::Compute(BlockMatrix A) {  // :119-133
   for (size_t i = 0; i < n_cols; ++i) {
     std::string key = NextKey(A);
     BlockMatrix Di_inv;
-    Di_inv(key, key) = A(key, key).Inverse();
+    {
+      const ShardSpec& sh = ShardSpec::Get();
+      const LinearMap& Akk = A(key, key);
+      // a replicated block of a sharded solve is the same matrix on every rank (its sharded
+      // contributions were all-reduced): split the work of inverting a large dense one
+      if (sh.active() && (!sh.keys().empty() || !sh.local().empty()) && !sh.IsSharded(key) &&
+          Akk.impl().type() == DENSE_MATRIX) {
+        Di_inv(key, key) =
+            LinearMap(static_cast<const DenseMatrixImpl&>(Akk.impl()).InverseDistributed());
+      } else {
+        Di_inv(key, key) = Akk.Inverse();
+      }
+    }
     BlockMatrix V = RemoveKey(&A, key);
     L_ = L_ + V * Di_inv;
     D_inv_ = D_inv_ + Di_inv;

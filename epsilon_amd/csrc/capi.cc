@@ -523,6 +523,37 @@ int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg) {
   });
 }
 
+int eps_bench_spd_inverse_columns(int64_t n, int64_t cnt, int iters, double* ms_avg) {
+  return Guard([&] {
+    const DType dt = ConfiguredDType();
+    DVec G = Synthetic(n * n, dt, 1.0);
+    DVec W0 = DVec::Zeros(n * n, dt);
+    k::Gemm(false, true, n, n, n, 1.0 / n, G, n, G, n, 0.0, W0, n, false);
+    k::AddDiag(W0, n, n, 1.0, nullptr);
+    DVec W = DVec::Empty(n * n, dt);
+    DVec Out = DVec::Empty(n * cnt, dt);
+    Runtime& rt = Runtime::Get();
+    double total = 0;
+    for (int i = 0; i < iters + 1; ++i) {
+      k::Copy(W, W0);
+      rt.Sync();
+      hipEvent_t a, b;
+      EPS_HIP(hipEventCreate(&a));
+      EPS_HIP(hipEventCreate(&b));
+      EPS_HIP(hipEventRecord(a, rt.stream()));
+      k::SpdInverseColumns(W, n, 0, cnt, Out);
+      EPS_HIP(hipEventRecord(b, rt.stream()));
+      EPS_HIP(hipEventSynchronize(b));
+      float e = 0;
+      EPS_HIP(hipEventElapsedTime(&e, a, b));
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+      if (i > 0) total += e;
+    }
+    *ms_avg = total / iters;
+  });
+}
+
 int eps_tv1d(const double* v, size_t n, double lam, double* x) {
   return Guard([&] {
     const DType dt = ConfiguredDType();

@@ -89,6 +89,9 @@ void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVe
 // W (n x n, ld = n, symmetric positive definite, full storage) -> W^{-1} in place.
 // Blocked Cholesky + triangular inverse + X^T X, all on device.  Throws if a pivot is <= 0.
 void SpdInverseInPlace(const DVec& W, int64_t n);
+// Columns [lo, lo + cnt) of W^-1 into Out (n x cnt, ld n); W is overwritten by its Cholesky
+// factor.  Cholesky + two blocked triangular solves on the cnt unit columns.
+void SpdInverseColumns(const DVec& W, int64_t n, int64_t lo, int64_t cnt, const DVec& Out);
 
 // ---- K6 / K12: elementwise and group prox kernels ------------------------------------------
 // reference prox/scaled_zone.cc:78-104 ; lam / alpha / beta are either uniform scalars or

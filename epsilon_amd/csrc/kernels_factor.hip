@@ -115,6 +115,17 @@ DVec Sub(const DVec& W, int64_t i, int64_t j, int64_t ld) {
 
 }  // namespace
 
+namespace {
+// Blocked Cholesky of W (n x n, ld n) in place (lower factor; the strictly upper part of the
+// diagonal blocks is scratch) and the inverses of the 64 x 64 diagonal blocks of L in dinv.
+void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag);
+void CheckFlag(int* flag);
+// X (n x n, zero on entry) receives the inverses of the diagonal blocks of size `cap` of the
+// factor L held in W (cap = n: all of inv(L)), grown from the 64 x 64 inverses in dinv by
+// inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11, X22].
+void DoublingInverse(const DVec& W, const DVec& X, int64_t n, const DVec& dinv, int64_t cap);
+}  // namespace
+
 void SpdInverseInPlace(const DVec& W, int64_t n) {
   EPS_CHECK(W.n >= n * n);
   if (n == 0) return;
@@ -129,8 +140,92 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
   auto flag_buf = rt.Alloc(sizeof(int));
   int* flag = static_cast<int*>(flag_buf->p);
   EPS_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-  DVec panel = DVec::Empty(std::max<int64_t>(n, 1) * NB, dt);
+  PotrfBlocked(W, n, dinv, flag);
 
+  // ---- 2. X = inv(L) by recursive doubling ---------------------------------------------------
+  DVec X = DVec::Zeros(n * n, dt);
+  DoublingInverse(W, X, n, dinv, n);
+
+  // ---- 3. W^-1 = X^T X ------------------------------------------------------------------------
+  // Row block p of the lower-triangular X is zero right of column (p+1)*B, so it only touches
+  // the leading (p+1)B x (p+1)B corner of X^T X: a third of the flops of the dense product.
+  {
+    const int64_t B = 1024;
+    Fill(W.Slice(0, n * n), 0.0);
+    for (int64_t p0 = 0; p0 < n; p0 += B) {
+      const int64_t pb = std::min<int64_t>(B, n - p0);
+      const int64_t cp = p0 + pb;  // columns with non-zeros in these rows
+      DVec Xp = Sub(X, p0, 0, ld);
+      Gemm(true, false, cp, cp, pb, 1.0, Xp, ld, Xp, ld, 1.0, W, ld, true);
+    }
+  }
+  SymmetrizeFromLower(W, n, ld);
+
+  CheckFlag(flag);
+}
+
+namespace {
+
+void CheckFlag(int* flag) {
+  hipStream_t s = Runtime::Get().stream();
+  int host_flag = 0;
+  EPS_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  EPS_HIP(hipStreamSynchronize(s));
+  EPS_CHECK_MSG(host_flag == 0, "dense inverse: matrix is not positive definite");
+}
+
+void DoublingInverse(const DVec& W, const DVec& X, int64_t n, const DVec& dinv, int64_t cap) {
+  hipStream_t s = Runtime::Get().stream();
+  const DType dt = W.dt;
+  const int64_t ld = n;
+  const int64_t nb = (n + NB - 1) / NB;
+  for (int64_t kblk = 0; kblk < nb; ++kblk) {
+    const int64_t k0 = kblk * NB;
+    const int64_t kb = std::min<int64_t>(NB, n - k0);
+    // copy the kb x kb inverse block (ld NB) into X's diagonal block (ld n)
+    EPS_HIP(hipMemcpy2DAsync(Sub(X, k0, k0, ld).data(), ld * DTypeSize(dt),
+                             dinv.Slice(kblk * NB * NB, NB * NB).data(), NB * DTypeSize(dt),
+                             kb * DTypeSize(dt), kb, hipMemcpyDeviceToDevice, s));
+  }
+  const int64_t half = std::min<int64_t>(cap, n) / 2 + NB;
+  DVec tmp2 = DVec::Empty(std::max<int64_t>(1, half * half), dt);
+  for (int64_t sz = NB; sz < cap; sz *= 2) {
+    for (int64_t r0 = 0; r0 + sz < n; r0 += 2 * sz) {
+      const int64_t s1 = sz;                                  // rows/cols of block 1
+      const int64_t s2 = std::min<int64_t>(sz, n - (r0 + sz));  // rows of block 2
+      DVec L21 = Sub(W, r0 + s1, r0, ld);
+      DVec X11 = Sub(X, r0, r0, ld);
+      DVec X22 = Sub(X, r0 + s1, r0 + s1, ld);
+      DVec X21 = Sub(X, r0 + s1, r0, ld);
+      EPS_CHECK(tmp2.n >= s2 * s1);
+      DVec T = tmp2.Slice(0, s2 * s1);
+      // X11 and X22 are lower triangular: column block j of X11 is zero above row j*cb and row
+      // block i of X22 is zero right of column (i+1)*rb, so the products only run over the
+      // non-zero part of K (62 % of the dense flops with four blocks).
+      const int64_t nsplit = sz >= 1024 ? 4 : 1;
+      const int64_t cb = (s1 + nsplit - 1) / nsplit;
+      for (int64_t c0 = 0; c0 < s1; c0 += cb) {
+        const int64_t cw = std::min<int64_t>(cb, s1 - c0);
+        Gemm(false, false, s2, cw, s1 - c0, 1.0, Sub(L21, 0, c0, ld), ld, Sub(X11, c0, c0, ld), ld,
+             0.0, T.Slice(c0 * s2, cw * s2), s2);
+      }
+      const int64_t rb = (s2 + nsplit - 1) / nsplit;
+      for (int64_t r1 = 0; r1 < s2; r1 += rb) {
+        const int64_t rw = std::min<int64_t>(rb, s2 - r1);
+        Gemm(false, false, rw, s1, r1 + rw, -1.0, Sub(X22, r1, 0, ld), ld, T, s2, 0.0,
+             Sub(X21, r1, 0, ld), ld);
+      }
+    }
+  }
+
+}
+
+void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  const DType dt = W.dt;
+  const int64_t ld = n;
+  DVec panel = DVec::Empty(std::max<int64_t>(n, 1) * NB, dt);
   // ---- 1. blocked Cholesky ------------------------------------------------------------------
   // Two-level blocking: 64-wide steps update only the rest of their 256-wide outer panel; the
   // trailing matrix sees one rank-256 update per outer panel (a rank-64 update of the whole
@@ -173,65 +268,70 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
     }
   }
 
-  // ---- 2. X = inv(L) by recursive doubling ---------------------------------------------------
+}
+
+}  // namespace
+
+// Columns [lo, lo + cnt) of W^-1 (n x cnt, ld n) without forming the rest: Cholesky, then the two
+// triangular solves L Y = E, L^T Z = Y on the cnt unit columns, 64 rows at a time with the
+// inverted diagonal blocks (every step is two small GEMMs).  W is overwritten by its factor.
+// Used when the inverse of a replicated matrix is split over the ranks of a sharded solve: each
+// rank solves for its own slab of columns and the slabs are all-gathered.
+void SpdInverseColumns(const DVec& W, int64_t n, int64_t lo, int64_t cnt, const DVec& Out) {
+  EPS_CHECK(W.n >= n * n && Out.n >= n * cnt && Out.dt == W.dt && lo >= 0 && lo + cnt <= n);
+  if (n == 0) return;
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  ProfScope prof("spd_inverse_columns", n, cnt);
+  const DType dt = W.dt;
+  const int64_t ld = n;
+  const int64_t nb = (n + NB - 1) / NB;
+  DVec dinv = DVec::Empty(nb * NB * NB, dt);
+  auto flag_buf = rt.Alloc(sizeof(int));
+  int* flag = static_cast<int*>(flag_buf->p);
+  EPS_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+  PotrfBlocked(W, n, dinv, flag);
+  if (cnt == 0) {
+    CheckFlag(flag);
+    return;
+  }
+  // B = E[:, lo : lo + cnt]
+  Fill(Out.Slice(0, n * cnt), 0.0);
+  AddDiag(Sub(Out, lo, 0, ld), cnt, ld, 1.0, nullptr);
+  // inverses of the BS x BS diagonal blocks of L (a few doubling levels), then BS rows per step
+  const int64_t BS = 512;
   DVec X = DVec::Zeros(n * n, dt);
-  for (int64_t kblk = 0; kblk < nb; ++kblk) {
-    const int64_t k0 = kblk * NB;
-    const int64_t kb = std::min<int64_t>(NB, n - k0);
-    // copy the kb x kb inverse block (ld NB) into X's diagonal block (ld n)
-    EPS_HIP(hipMemcpy2DAsync(Sub(X, k0, k0, ld).data(), ld * DTypeSize(dt),
-                             dinv.Slice(kblk * NB * NB, NB * NB).data(), NB * DTypeSize(dt),
-                             kb * DTypeSize(dt), kb, hipMemcpyDeviceToDevice, s));
+  DoublingInverse(W, X, n, dinv, BS);
+  DVec tmp = DVec::Empty(BS * cnt, dt);
+  const size_t es = DTypeSize(dt);
+  const int64_t nbs = (n + BS - 1) / BS;
+  auto store_rows = [&](int64_t k0, int64_t kb) {  // Out[k0 : k0 + kb, :] = tmp (kb x cnt)
+    EPS_HIP(hipMemcpy2DAsync(Sub(Out, k0, 0, ld).data(), ld * es, tmp.data(), kb * es, kb * es, cnt,
+                             hipMemcpyDeviceToDevice, s));
+  };
+  // forward L Y = E: rows above lo stay zero
+  for (int64_t kblk = lo / BS; kblk < nbs; ++kblk) {
+    const int64_t k0 = kblk * BS;
+    const int64_t kb = std::min<int64_t>(BS, n - k0);
+    Gemm(false, false, kb, cnt, kb, 1.0, Sub(X, k0, k0, ld), ld, Sub(Out, k0, 0, ld), ld, 0.0, tmp,
+         kb);
+    store_rows(k0, kb);  // Y_k = inv(L_kk) B_k
+    const int64_t rem = n - (k0 + kb);
+    if (rem > 0)  // B[k+1:, :] -= L[k+1:, k] Y_k
+      Gemm(false, false, rem, cnt, kb, -1.0, Sub(W, k0 + kb, k0, ld), ld, tmp, kb, 1.0,
+           Sub(Out, k0 + kb, 0, ld), ld);
   }
-  DVec tmp2 = DVec::Empty(std::max<int64_t>(1, (n / 2 + NB) * (n / 2 + NB)), dt);
-  for (int64_t sz = NB; sz < n; sz *= 2) {
-    for (int64_t r0 = 0; r0 + sz < n; r0 += 2 * sz) {
-      const int64_t s1 = sz;                                  // rows/cols of block 1
-      const int64_t s2 = std::min<int64_t>(sz, n - (r0 + sz));  // rows of block 2
-      DVec L21 = Sub(W, r0 + s1, r0, ld);
-      DVec X11 = Sub(X, r0, r0, ld);
-      DVec X22 = Sub(X, r0 + s1, r0 + s1, ld);
-      DVec X21 = Sub(X, r0 + s1, r0, ld);
-      EPS_CHECK(tmp2.n >= s2 * s1);
-      DVec T = tmp2.Slice(0, s2 * s1);
-      // X11 and X22 are lower triangular: column block j of X11 is zero above row j*cb and row
-      // block i of X22 is zero right of column (i+1)*rb, so the products only run over the
-      // non-zero part of K (62 % of the dense flops with four blocks).
-      const int64_t nsplit = sz >= 1024 ? 4 : 1;
-      const int64_t cb = (s1 + nsplit - 1) / nsplit;
-      for (int64_t c0 = 0; c0 < s1; c0 += cb) {
-        const int64_t cw = std::min<int64_t>(cb, s1 - c0);
-        Gemm(false, false, s2, cw, s1 - c0, 1.0, Sub(L21, 0, c0, ld), ld, Sub(X11, c0, c0, ld), ld,
-             0.0, T.Slice(c0 * s2, cw * s2), s2);
-      }
-      const int64_t rb = (s2 + nsplit - 1) / nsplit;
-      for (int64_t r1 = 0; r1 < s2; r1 += rb) {
-        const int64_t rw = std::min<int64_t>(rb, s2 - r1);
-        Gemm(false, false, rw, s1, r1 + rw, -1.0, Sub(X22, r1, 0, ld), ld, T, s2, 0.0,
-             Sub(X21, r1, 0, ld), ld);
-      }
-    }
+  // backward L^T Z = Y
+  for (int64_t kblk = nbs - 1; kblk >= 0; --kblk) {
+    const int64_t k0 = kblk * BS;
+    const int64_t kb = std::min<int64_t>(BS, n - k0);
+    Gemm(true, false, kb, cnt, kb, 1.0, Sub(X, k0, k0, ld), ld, Sub(Out, k0, 0, ld), ld, 0.0, tmp,
+         kb);
+    store_rows(k0, kb);  // Z_k = inv(L_kk)^T Y_k
+    if (k0 > 0)  // Y[0:k, :] -= L[k, 0:k]^T Z_k
+      Gemm(true, false, k0, cnt, kb, -1.0, Sub(W, k0, 0, ld), ld, tmp, kb, 1.0, Out, ld);
   }
-
-  // ---- 3. W^-1 = X^T X ------------------------------------------------------------------------
-  // Row block p of the lower-triangular X is zero right of column (p+1)*B, so it only touches
-  // the leading (p+1)B x (p+1)B corner of X^T X: a third of the flops of the dense product.
-  {
-    const int64_t B = 1024;
-    Fill(W.Slice(0, n * n), 0.0);
-    for (int64_t p0 = 0; p0 < n; p0 += B) {
-      const int64_t pb = std::min<int64_t>(B, n - p0);
-      const int64_t cp = p0 + pb;  // columns with non-zeros in these rows
-      DVec Xp = Sub(X, p0, 0, ld);
-      Gemm(true, false, cp, cp, pb, 1.0, Xp, ld, Xp, ld, 1.0, W, ld, true);
-    }
-  }
-  SymmetrizeFromLower(W, n, ld);
-
-  int host_flag = 0;
-  EPS_HIP(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-  EPS_HIP(hipStreamSynchronize(s));
-  EPS_CHECK_MSG(host_flag == 0, "dense inverse: matrix is not positive definite");
+  CheckFlag(flag);
 }
 
 }  // namespace k

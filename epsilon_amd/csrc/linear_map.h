@@ -182,6 +182,10 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   std::string DebugString() const override;
   std::shared_ptr<const LinearMapImpl> Transpose() const override;
   std::shared_ptr<const LinearMapImpl> Inverse() const override;
+  // COLLECTIVE: the same inverse for a matrix that is replicated on every rank of a sharded
+  // solve - each rank solves for its own slab of columns (Cholesky + triangular solves) and the
+  // slabs are all-gathered, instead of every rank forming the whole inverse.
+  std::shared_ptr<const LinearMapImpl> InverseDistributed() const;
   bool Equals(const LinearMapImpl& other) const override;
   void Apply(double alpha, const DVec& x, double beta, const DVec& y) const override;
   std::vector<double> AsDenseHost() const override;

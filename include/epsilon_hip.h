@@ -178,6 +178,7 @@ int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, in
                    int iters, double* ms_avg);
 /* SPD inverse of an n x n synthetic matrix. */
 int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg);
+int eps_bench_spd_inverse_columns(int64_t n, int64_t cnt, int iters, double* ms_avg);
 
 /* Exact 1-D total-variation prox of v (n float64) with weight lam
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */

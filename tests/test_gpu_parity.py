@@ -480,6 +480,27 @@ def test_sharded_hip_solve_matches_single_gpu(solve_mod, tmp_path, world):
     np.testing.assert_allclose(x1, np.frombuffer(x["var:x"]), rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_sharded_solve_distributed_inverse(solve_mod, tmp_path, dt):
+    """From 1024 rows the explicit inverse of the replicated Schur complement is split over the
+    ranks (Cholesky + triangular solves for a slab of columns each, all-gather): 3 ranks sharing
+    this GPU against the single-process oracle."""
+    from tests import mp_util
+    m, n = 1100, 2300
+    x0, x1, status, parts = mp_util.run_ranks(3, "hip", str(tmp_path), m, n, seed=5,
+                                              env_extra={"EPS_TEST_DTYPE": dt,
+                                                         "EPSILON_HIP_DIST_INVERSE": "2"})
+    prob, info = problems.lasso(m, n, seed=5)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams().SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    for s, p in zip(status, parts):
+        assert int(p["state"]) == wire.SolverStatus.OPTIMAL and int(s[0]) == S.num_iterations
+    tol = dict(rtol=1e-7, atol=1e-9) if dt == "f64" else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(x0, np.frombuffer(x[problems.LASSO_COPY]), **tol)
+    np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), **tol)
+
+
 def test_rccl_backend_single_rank(solve_mod):
     """RCCL backend end to end (dlopen, unique id, ncclCommInitRank, ncclAllReduce on the solver
     stream) on a 1-rank communicator with the sharded code path forced on."""

@@ -37,6 +37,14 @@ def inverse(n, iters=2, dtype="f32"):
     print("spd_inverse n=%d %s: %.2f ms" % (n, dtype, ms.value), flush=True)
 
 
+def inverse_columns(n, cnt, iters=2, dtype="f32"):
+    _solve.set_option("dtype", dtype)
+    ms = ctypes.c_double()
+    _solve._check(L.eps_bench_spd_inverse_columns(ctypes.c_int64(n), ctypes.c_int64(cnt), ctypes.c_int(iters),
+                                                  ctypes.byref(ms)))
+    print("spd_inverse_columns n=%d cnt=%d %s: %.2f ms" % (n, cnt, dtype, ms.value), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemv", "gemm", "inverse"]
     if "gemv" in what:
@@ -55,3 +63,6 @@ if __name__ == "__main__":
     if "inverse" in what:
         inverse(10000)
         inverse(2048)
+        inverse_columns(10000, 1250)
+        inverse_columns(10000, 2500)
+        inverse_columns(10000, 5000)
