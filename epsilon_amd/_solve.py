@@ -253,6 +253,10 @@ def shard_keys(keys):
     _check(lib().eps_shard_keys(arr, ctypes.c_size_t(len(keys))))
 
 
+def shard_consensus_terms(on=True):
+    _check(lib().eps_shard_consensus_terms(ctypes.c_int(1 if on else 0)))
+
+
 def profile_enable(on=True):
     _check(lib().eps_profile_enable(ctypes.c_int(1 if on else 0)))
 

@@ -25,6 +25,13 @@ std::set<std::string> InferShardedArgs(const BlockMatrix& H) {
   std::set<std::string> out;
   const ShardSpec& sh = ShardSpec::Get();
   if (!sh.active()) return out;
+  if (sh.consensus_terms() && !H.data().empty()) {
+    // consensus form: a term over sharded variables only is this rank's own term, and so are
+    // its argument rows, whatever the type of the maps into them
+    bool all_sharded = true;
+    for (const auto& col : H.data()) all_sharded = all_sharded && sh.IsSharded(col.first);
+    if (all_sharded) return H.row_keys();
+  }
   std::map<std::string, int> vote;  // 1 sharded, 2 replicated
   for (const auto& col : H.data()) {
     if (!sh.IsSharded(col.first)) continue;
@@ -194,6 +201,7 @@ class ProxADMMSolver final : public Solver {
     prox_.clear();
     AiT_.clear();
     arg_shards_.clear();
+    term_per_rank_.clear();
     std::set<std::string> constr_vars = A_.col_keys();
     for (int i = 0; i < N_; ++i) {
       const pb::Expression& f_expr = problem_.objective.arg[i];
@@ -212,6 +220,13 @@ class ProxADMMSolver final : public Solver {
       prox_.emplace_back(CreateProxOperator(f_expr.prox_function.prox_function_type,
                                             f_expr.prox_function.epigraph));
       arg_shards_.push_back(InferShardedArgs(H.A));
+      {
+        // consensus form: is this one of the per-rank terms f_g(x_g)?
+        const ShardSpec& sh = ShardSpec::Get();
+        bool own = sh.active() && sh.consensus_terms() && !vars.empty();
+        for (const auto& var : vars) own = own && sh.IsSharded(var.first);
+        term_per_rank_.push_back(own);
+      }
       {
         LocalShardScope scope(arg_shards_.back());
         prox_.back()->Init(ProxOperatorArg(f_expr.prox_function, data_.get(), H, A));
@@ -242,6 +257,8 @@ class ProxADMMSolver final : public Solver {
     if (env && env[0] == '0') return;
     if (data_->dtype() != F32 || N_ != 2 || problem_.constraint.size() != 1) return;
     if (!b_.data().empty()) return;
+    // consensus form: the threshold step averages over the ranks, which the fused pass does not
+    if (ShardSpec::Get().active() && ShardSpec::Get().consensus_terms()) return;
     FusedState f;
     if (!prox_[0]->DescribeLeastSquares(&f.ls) || !prox_[1]->DescribeScaledZone(&f.sz)) return;
     const std::string ck = affine::constraint_key(0);
@@ -417,7 +434,15 @@ class ProxADMMSolver final : public Solver {
     rt.FetchSlots();
 
     double max_norm = std::sqrt(rt.SlotValue(s_b));
-    for (int i = 0; i < N_; ++i) max_norm = std::fmax(max_norm, std::sqrt(rt.SlotValue(s_Ax[i])));
+    double own_max = -1;
+    for (int i = 0; i < N_; ++i) {
+      if (term_per_rank_[i])  // one term per rank: the reference's max runs over all of them
+        own_max = std::fmax(own_max, std::sqrt(rt.SlotLocalValue(s_Ax[i])));
+      else
+        max_norm = std::fmax(max_norm, std::sqrt(rt.SlotValue(s_Ax[i])));
+    }
+    if (ShardSpec::Get().active() && ShardSpec::Get().consensus_terms())
+      max_norm = std::fmax(max_norm, rt.comm()->AllReduceMaxHost(own_max));
     double s2 = 0;
     for (int s : s_s) {
       const double si = std::sqrt(rt.SlotValue(s));
@@ -439,6 +464,7 @@ class ProxADMMSolver final : public Solver {
   std::vector<BlockMatrix> AiT_;
   std::vector<std::unique_ptr<ProxOperator>> prox_;
   std::vector<std::set<std::string>> arg_shards_;
+  std::vector<bool> term_per_rank_;
   struct FusedState {
     LeastSquaresDesc ls;
     ScaledZoneDesc sz;

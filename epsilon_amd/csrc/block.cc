@@ -234,6 +234,19 @@ LinearMap AllReduceMap(const LinearMap& P, const std::string& r, const std::stri
     comm->AllReduceSum(buf);
     return LinearMap::Dense(buf, D->m(), D->n());
   }
+  if (P.impl().type() == SCALAR_MATRIX) {
+    // consensus rows (x_g - z = 0 on every rank): sum of the per-rank scalars
+    double a = static_cast<const ScalarMatrixImpl&>(P.impl()).alpha();
+    DVec d = DVec::FromHost(&a, 1, F64);
+    comm->AllReduceSum(d);
+    return LinearMap::Scalar(d.ToHost()[0], P.impl().n());
+  }
+  if (P.impl().type() == DIAGONAL_MATRIX) {
+    const auto& D = static_cast<const DiagonalMatrixImpl&>(P.impl());
+    DVec buf = DVec::FromHost(D.diagonal().data(), static_cast<int64_t>(D.diagonal().size()), F64);
+    comm->AllReduceSum(buf);
+    return LinearMap::Diagonal(buf.ToHost(), D.dtype());
+  }
   if (P.impl().type() == KRONECKER_PRODUCT) {
     const auto& K = static_cast<const KroneckerProductImpl&>(P.impl());
     const bool a_s = K.A().impl().type() == SCALAR_MATRIX, b_s = K.B().impl().type() == SCALAR_MATRIX;

@@ -343,6 +343,10 @@ int eps_shard_keys(const char* const* keys, size_t nkeys) {
   });
 }
 
+int eps_shard_consensus_terms(int on) {
+  return Guard([&] { ShardSpec::Get().set_consensus_terms(on != 0); });
+}
+
 int eps_profile_enable(int on) {
   return Guard([&] { Runtime::Get().set_profiling(on != 0); });
 }

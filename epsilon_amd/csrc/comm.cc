@@ -13,6 +13,18 @@ ShardSpec& ShardSpec::Get() {
   return *s;
 }
 
+double Comm::AllReduceMaxHost(double local) {
+  const int G = size();
+  std::vector<double> h(static_cast<size_t>(G), 0.0);
+  h[static_cast<size_t>(rank())] = local;
+  DVec d = DVec::FromHost(h.data(), G, F64);
+  AllReduceSum(d);
+  h = d.ToHost();
+  double mx = h[0];
+  for (double v : h) mx = v > mx ? v : mx;
+  return mx;
+}
+
 bool ShardSpec::active() const {
   Comm* c = Runtime::Get().comm();
   if (c == nullptr) return false;

@@ -31,6 +31,9 @@ class Comm {
   void AllReduceSum(const DVec& v) { AllReduceSum(v.data(), static_cast<size_t>(v.n), v.dt); }
   // recv[r*count .. (r+1)*count) = rank r's send[0..count); recv may not alias send.
   virtual void AllGather(const void* send_dev, void* recv_dev, size_t count, DType dt) = 0;
+  // Maximum over ranks of one host value (synchronises).  Built on AllReduceSum of a one-hot
+  // vector, so every backend - including the sum-only host callback - has it.
+  double AllReduceMaxHost(double local);
 };
 
 typedef void (*HostAllReduceFn)(void* host_buf, size_t count, int dtype, void* ctx);
@@ -44,13 +47,21 @@ Comm* NewHostCallbackComm(int rank, int size, HostAllReduceFn fn, void* ctx);
 class ShardSpec {
  public:
   static ShardSpec& Get();
-  void Clear() { keys_.clear(); }
+  void Clear() {
+    keys_.clear();
+    consensus_terms_ = false;
+  }
   void Add(const std::string& key) { keys_.insert(key); }
   bool active() const;                       // a communicator with size > 1 is installed
   bool IsSharded(const std::string& key) const {
     return keys_.count(key) != 0 || local_.count(key) != 0;
   }
   const std::set<std::string>& keys() const { return keys_; }
+  // Consensus form (SURVEY.md 8(e) mode E2): an objective term all of whose variables are
+  // sharded is a DIFFERENT term on every rank (f_g(x_g), its argument rows private to the rank)
+  // instead of this rank's slice of one global term.
+  void set_consensus_terms(bool on) { consensus_terms_ = on; }
+  bool consensus_terms() const { return consensus_terms_; }
   // Keys whose meaning is local to one prox operator ("arg:<k>" rows of its H): set around that
   // operator's Init / Apply by LocalShardScope.
   void set_local(std::set<std::string> local) { local_ = std::move(local); }
@@ -66,6 +77,7 @@ class ShardSpec {
  private:
   std::set<std::string> keys_;
   std::set<std::string> local_;
+  bool consensus_terms_ = false;
   std::map<std::string, int64_t> global_dim_;
 };
 

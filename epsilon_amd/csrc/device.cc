@@ -30,10 +30,10 @@ Runtime::Runtime() {
   EPS_HIP(hipSetDevice(device_));
   EPS_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   EPS_HIP(hipMalloc(reinterpret_cast<void**>(&slots_dev_), 2 * kMaxSlots * sizeof(double)));
-  EPS_HIP(hipHostMalloc(reinterpret_cast<void**>(&slots_host_), 2 * kMaxSlots * sizeof(double),
+  EPS_HIP(hipHostMalloc(reinterpret_cast<void**>(&slots_host_), 3 * kMaxSlots * sizeof(double),
                         hipHostMallocDefault));
   EPS_HIP(hipMemsetAsync(slots_dev_, 0, 2 * kMaxSlots * sizeof(double), stream_));
-  std::memset(slots_host_, 0, 2 * kMaxSlots * sizeof(double));
+  std::memset(slots_host_, 0, 3 * kMaxSlots * sizeof(double));
 }
 
 Runtime::~Runtime() {}
@@ -108,6 +108,10 @@ void Runtime::ResetSlots() {
 void Runtime::FetchSlots() {
   if (slots_used_ > 0) {
     const bool sharded = ShardSpec::Get().active();
+    // consensus form: this rank's own share of the sharded half is kept too (per-rank terms)
+    if (sharded && ShardSpec::Get().consensus_terms())
+      EPS_HIP(hipMemcpyAsync(slots_host_ + 2 * kMaxSlots, slots_dev_ + kMaxSlots,
+                             slots_used_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
     if (sharded) comm_->AllReduceSum(slots_dev_ + kMaxSlots, slots_used_, F64);
     EPS_HIP(hipMemcpyAsync(slots_host_, slots_dev_, slots_used_ * sizeof(double),
                            hipMemcpyDeviceToHost, stream_));

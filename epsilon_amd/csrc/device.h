@@ -57,6 +57,8 @@ class Runtime {
   void ResetSlots();  // rewinds and zeroes (on the stream)
   void FetchSlots();
   double SlotValue(int i) const { return slots_host_[i] + slots_host_[kMaxSlots + i]; }
+  // before the sum over ranks (valid when ShardSpec::consensus_terms() is set)
+  double SlotLocalValue(int i) const { return slots_host_[i] + slots_host_[2 * kMaxSlots + i]; }
 
   void Sync();
 

@@ -67,6 +67,48 @@ def lasso(m, n, rho=1.0, seed=0):
     return prob, dict(A=A, b=b, lam=lam)
 
 
+CONSENSUS_Z = "var:z"
+
+
+def consensus_row_range(m, rank, world):
+    per = -(-m // world)
+    lo = min(m, rank * per)
+    return lo, min(m, lo + per)
+
+
+def consensus_lasso_local(A_g, b_g, lam, x_key="var:x_local"):
+    """One rank's problem of the consensus-form lasso (examples split by rows):
+    sum_square(A_g x_g - b_g) + lam*norm_1(z)  s.t.  x_g - z = 0.  x_g and the constraint row are
+    sharded keys, z is replicated (include/epsilon_hip.h, eps_shard_consensus_terms)."""
+    mg, n = A_g.shape
+    x = ir.variable(n, 1, x_key)
+    z = ir.variable(n, 1, CONSENSUS_Z)
+    f = ir.prox(ProxFunction.SUM_SQUARE,
+                ir.add(ir.linear_map(ir.dense_matrix(A_g), x),
+                       ir.linear_map(ir.scalar(-1, mg), ir.constant(b_g))), alpha=1.0)
+    h = ir.prox(ProxFunction.NORM_1, z, alpha=lam)
+    c = ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, n), z)))
+    return ir.Problem([f, h], [c])
+
+
+def consensus_lasso(A, b, lam, world):
+    """The same problem stacked for ONE process: terms f_1..f_G, h and G consensus constraints
+    (what the per-rank solves must reproduce sweep for sweep)."""
+    m, n = A.shape
+    z = ir.variable(n, 1, CONSENSUS_Z)
+    terms, cons = [], []
+    for g in range(world):
+        lo, hi = consensus_row_range(m, g, world)
+        x = ir.variable(n, 1, "var:x_%d" % g)
+        terms.append(ir.prox(ProxFunction.SUM_SQUARE,
+                             ir.add(ir.linear_map(ir.dense_matrix(A[lo:hi]), x),
+                                    ir.linear_map(ir.scalar(-1, hi - lo), ir.constant(b[lo:hi]))),
+                             alpha=1.0))
+        cons.append(ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, n), z))))
+    terms.append(ir.prox(ProxFunction.NORM_1, z, alpha=lam))
+    return ir.Problem(terms, cons)
+
+
 def lasso_objective(A, b, lam, x):
     r = A.dot(x) - b
     return float(r.dot(r) + lam * np.abs(x).sum())

@@ -142,6 +142,15 @@ int eps_comm_warmup(size_t count);
 int eps_comm_shutdown(void);
 /* Replace the set of sharded block keys (variable ids and "constraint:<i>" rows). */
 int eps_shard_keys(const char* const* keys, size_t nkeys);
+/* Consensus form (call after eps_shard_keys, which resets it): every rank passes
+ *   minimise f_g(x_g) + h(z)  subject to  x_g - z = 0
+ * with x_g and the constraint row sharded and z replicated.  An objective term over sharded
+ * variables only is then this rank's OWN term (its argument rows stay on the rank; nothing of
+ * it is all-reduced); the update of z all-reduces the n entries of sum_g (x_g + u_g) - the
+ * z-averaging step - and the residual norms / the max over per-term norms are reduced across
+ * ranks.  The iterates are those of the single-process solve of the stacked problem
+ * (terms f_1..f_G, h; G consensus constraints). */
+int eps_shard_consensus_terms(int on);
 
 /* ---- live kernel timing ---------------------------------------------------------------------- */
 /* When enabled, every hot kernel launch is bracketed by HIP events on the solver's stream.

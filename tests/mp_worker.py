@@ -3,6 +3,9 @@ MASTER_ADDR / MASTER_PORT in the environment).
 
 mode "oracle": numpy emulation of the column-sharded (E1) lasso sweep with gloo collectives -
                checks the partitioning and where the collectives sit (runs on CPU).
+mode "oracle_consensus": numpy emulation of the consensus-form (E2) lasso, rows of A split over
+               the ranks, z-averaging and residual sums over gloo (runs on CPU).
+mode "hip_consensus": the HIP solver on the per-rank consensus problem (host-callback comm).
 mode "hip"   : the real HIP solver, one rank per process, collectives through the host-callback
                backend over gloo (ranks may share one GPU).
 Each rank writes its slice of the result to <out>/rank<r>.npz.
@@ -37,6 +40,66 @@ def main():
         dist.all_reduce(t)
         return t.numpy()
 
+    if mode in ("oracle_consensus", "hip_consensus"):
+        lam = 0.3 * np.abs(A.T.dot(b)).max()
+        lo, hi = problems.consensus_row_range(m, rank, world)
+        Ag, bg = A[lo:hi], b[lo:hi]
+        if mode == "hip_consensus":
+            from epsilon_amd import _solve
+            _solve.set_option("dtype", os.environ.get("EPS_TEST_DTYPE", "f64"))
+            edist.init_comm(rank, world, backend="host")
+            prob = problems.consensus_lasso_local(Ag, bg, lam)
+            _solve.shard_keys(["var:x_local", "constraint:0"])
+            _solve.shard_consensus_terms(True)
+            params = wire.SolverParams(max_iterations=max_iter)
+            st, x = _solve.solve(prob.SerializeToString(), [], params.SerializeToString(),
+                                 prob.expression_data())
+            S = wire.SolverStatus.FromString(st)
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+                     x0=np.frombuffer(x["var:x_local"]), x1=np.frombuffer(x[problems.CONSENSUS_Z]),
+                     lo=lo, hi=hi,
+                     status=np.array([S.num_iterations, S.residuals.r_norm, S.residuals.s_norm,
+                                      S.residuals.epsilon_primal, S.residuals.epsilon_dual]),
+                     state=S.state)
+            _solve.comm_shutdown()
+        else:
+            # per-rank sweep of [f_g, h] with x_g - z = 0 (prox_admm.cc:135-147 unrolled); the only
+            # data-path collective is the sum over ranks inside the z update
+            G = world
+            Minv = np.linalg.inv(np.eye(hi - lo) + 2 * Ag.dot(Ag.T))
+            xg = np.zeros(n); z = np.zeros(n); u = np.zeros(n); y0 = np.zeros(n); y1 = np.zeros(n)
+            it, status = 0, None
+            while it < max_iter:
+                y1_prev = y1.copy()
+                u = u - y0 - y1
+                u = u + y0
+                w = Minv.dot(bg - Ag.dot(u))
+                xg = u + 2 * Ag.T.dot(w)
+                y0 = xg.copy()
+                u = u - y0
+                u = u + y1
+                v = allreduce(-u) / G                    # z-averaging: n doubles
+                z = np.sign(v) * np.maximum(np.abs(v) - lam / G, 0)
+                y1 = -z
+                u = u - y1
+                if it % 10 == 0:
+                    s = allreduce(np.array([np.sum((xg - z) ** 2), np.sum((y1 - y1_prev) ** 2),
+                                            np.sum(z ** 2), np.sum(u ** 2)]))
+                    usum = allreduce(u.copy())
+                    onehot = np.zeros(G); onehot[rank] = np.sqrt(np.sum(xg ** 2))
+                    xmax = allreduce(onehot).max()       # max over the per-rank terms
+                    r, sn = np.sqrt(s[0]), np.sqrt(s[1])
+                    ep = 1e-4 * np.sqrt(G * n) + 1e-2 * max(xmax, np.sqrt(s[2]))
+                    ed = 1e-4 * np.sqrt((G + 1) * n) + 1e-2 * np.sqrt(s[3] + np.sum(usum ** 2))
+                    status = (it, r, sn, ep, ed)
+                    if r <= ep and sn <= ed:
+                        break
+                it += 1
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x0=xg, x1=z, lo=lo, hi=hi,
+                     status=np.array(status))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "hip_mnist":
         # BASELINE.json configs[3] shape: multiclass hinge, SAMPLES sharded over the ranks
         from epsilon_amd import _solve

@@ -42,3 +42,30 @@ def test_sharded_sweep_equals_single_process(tmp_path, world):
                                    rtol=1e-9)
     np.testing.assert_allclose(x0, np.frombuffer(x["separate:var:x:sum_square"]), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(x1, np.frombuffer(x["var:x"]), rtol=1e-9, atol=1e-11)
+
+
+def consensus_reference(m, n, seed, world):
+    A, b = problems.regression_data(m, n, seed=seed)
+    lam = 0.3 * np.abs(A.T.dot(b)).max()
+    prob = problems.consensus_lasso(A, b, lam, world)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams().SerializeToString(),
+                      prob.expression_data())
+    return wire.SolverStatus.FromString(st), x
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_consensus_sweep_equals_single_process(tmp_path, world):
+    """Consensus form (SURVEY.md 8(e) mode E2): rows of A split over the ranks, one term f_g per
+    rank, z-averaging all-reduce.  The per-rank sweeps must reproduce the single-process solve
+    of the stacked problem (terms f_1..f_G, h; G consensus constraints) sweep for sweep."""
+    m, n = 61, 23
+    x0, x1, status, parts = mp_util.run_ranks(world, "oracle_consensus", str(tmp_path), m, n, seed=4)
+    S, x = consensus_reference(m, n, 4, world)
+    for s in status:
+        assert int(s[0]) == S.num_iterations
+        np.testing.assert_allclose(s[1:], [S.residuals.r_norm, S.residuals.s_norm,
+                                           S.residuals.epsilon_primal, S.residuals.epsilon_dual],
+                                   rtol=1e-9)
+    for g, p in enumerate(parts):
+        np.testing.assert_allclose(p["x0"], np.frombuffer(x["var:x_%d" % g]), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(p["x1"], np.frombuffer(x[problems.CONSENSUS_Z]), rtol=1e-9, atol=1e-11)

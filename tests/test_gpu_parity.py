@@ -501,6 +501,33 @@ def test_sharded_solve_distributed_inverse(solve_mod, tmp_path, dt):
     np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), **tol)
 
 
+@pytest.mark.parametrize("world,dt", [(2, "f64"), (3, "f64"), (3, "f32")])
+def test_consensus_form_solve(solve_mod, tmp_path, world, dt):
+    """Consensus form (mode E2): every rank holds its own term f_g (a row block of A), x_g and
+    the consensus row sharded, z replicated and averaged by one all-reduce of n entries per
+    sweep.  `world` processes sharing this GPU against the oracle's single-process solve of the
+    stacked problem: same stopping sweep, residuals and iterates."""
+    from tests import mp_util
+    m, n = 61, 23
+    x0, x1, status, parts = mp_util.run_ranks(world, "hip_consensus", str(tmp_path), m, n, seed=4,
+                                              env_extra={"EPS_TEST_DTYPE": dt})
+    A, b = problems.regression_data(m, n, seed=4)
+    lam = 0.3 * np.abs(A.T.dot(b)).max()
+    prob = problems.consensus_lasso(A, b, lam, world)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams().SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    tol = dict(rtol=1e-8, atol=1e-10) if dt == "f64" else dict(rtol=2e-3, atol=2e-4)
+    for g, (s, p) in enumerate(zip(status, parts)):
+        assert int(p["state"]) == wire.SolverStatus.OPTIMAL
+        assert int(s[0]) == S.num_iterations
+        np.testing.assert_allclose(s[1:], [S.residuals.r_norm, S.residuals.s_norm,
+                                           S.residuals.epsilon_primal, S.residuals.epsilon_dual],
+                                   rtol=1e-8 if dt == "f64" else 5e-3)
+        np.testing.assert_allclose(p["x0"], np.frombuffer(x["var:x_%d" % g]), **tol)
+        np.testing.assert_allclose(p["x1"], np.frombuffer(x[problems.CONSENSUS_Z]), **tol)
+
+
 def test_rccl_backend_single_rank(solve_mod):
     """RCCL backend end to end (dlopen, unique id, ncclCommInitRank, ncclAllReduce on the solver
     stream) on a 1-rank communicator with the sharded code path forced on."""
