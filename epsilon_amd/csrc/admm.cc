@@ -151,8 +151,18 @@ class ProxADMMSolver final : public Solver {
     const double t0 = Now();
     if (op_cache_.size() > 64) op_cache_.Clear();
     OpCacheScope cache_scope(&op_cache_);
+    static const bool trace = std::getenv("EPSILON_HIP_INIT_TRACE") != nullptr;
+    auto mark = [&](const char* what) {  // host wall clock + device drain, debugging aid only
+      if (!trace) return;
+      const double th = Now();
+      Runtime::Get().Sync();
+      std::fprintf(stderr, "[init] %-16s host %.2f ms  drained %.2f ms\n", what, 1e3 * (th - t0),
+                   1e3 * (Now() - t0));
+    };
     InitConstraints();
+    mark("constraints");
     InitProxOperators();
+    mark("prox operators");
     if (!params_.warm_start || !vars_initialized_) {
       InitVariables();
       vars_initialized_ = true;
@@ -162,6 +172,7 @@ class ProxADMMSolver final : public Solver {
     status_ = pb::SolverStatus();
     initialized_ = true;
     TryEnableFused();
+    mark("fused state");
     if (params_.verbose && log_) {
       char buf[128];
       std::snprintf(buf, sizeof(buf), "constraints, m = %lld, variables, n = %lld",

@@ -488,7 +488,8 @@ int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, in
   return Guard([&] {
     const DType dt = ConfiguredDType();
     DVec A = Synthetic(M * K, dt, 1.0);
-    DVec B = Synthetic(K * N, dt, 1.0);
+    // lower_only == 2: SYRK proper, both operands are the same buffer (the Gram product)
+    DVec B = lower_only == 2 ? A : Synthetic(K * N, dt, 1.0);
     DVec C = DVec::Zeros(M * N, dt);
     const int64_t lda = trans_a ? K : M, ldb = trans_b ? N : K;
     *ms_avg = TimeLaunches(iters, [&] {

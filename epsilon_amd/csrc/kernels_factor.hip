@@ -5,11 +5,14 @@
 // and then applies the explicit inverse by dgemv every iteration.  Same contract here (the
 // cached operator is an explicit inverse, because a GEMV is the GPU-friendly apply), built as
 //
-//   1. blocked right-looking Cholesky  W = L L^T        (64-wide panels; the panel solve and the
-//      trailing update are GEMMs on the MFMA kernel, the 64x64 diagonal block is factored
-//      and inverted inside one workgroup's LDS),
+//   1. blocked Cholesky  W = L L^T: 256-wide outer panels, right-looking between panels (one
+//      rank-256 update of the trailing matrix per panel on the MFMA kernel) and left-looking in
+//      64-column steps inside a panel - per step one workgroup updates and factors the 64 x 64
+//      diagonal block (register resident, one wave) and one launch updates the rows below and
+//      solves them against the new block by forward substitution,
 //   2. X = L^-1 by recursive doubling: inv([L11 0; L21 L22]) = [X11 0; -X22 L21 X11, X22],
-//      bottom-up from the 64x64 diagonal inverses -- every step is two GEMMs,
+//      bottom-up from the 64x64 diagonal inverses (one batched launch) -- every level is two
+//      GEMMs, batched over the pairs of the level below 4096 rows,
 //   3. W^-1 = X^T X  (lower tiles, then mirrored).
 #include <hip/hip_runtime.h>
 
@@ -49,22 +52,16 @@ template <int N> struct StaticFor<N, N> {
   template <class F> __device__ static inline void Run(F&&) {}
 };
 
-// Factor the kb x kb block at W (ld) in place (lower Cholesky) and write inv(L) (dense NB x NB,
-// zeros above the diagonal, ld = NB) to Dinv.  ONE WAVE, register resident: lane i owns row i
-// of the block (64 registers); the pivot column is broadcast lane by lane with v_readlane, so
-// the 64 elimination steps need no LDS and no barriers (the previous LDS version spent ~190 us
-// per block in ~400 barriers; this one ~4000 readlane + FMA pairs).  *flag != 0 on a bad pivot.
-template <class T>
-__global__ __launch_bounds__(64) void PotrfDiagKernel(T* W, int64_t ld, int kb, T* Dinv,
-                                                      int* flag) {
-  const int lane = threadIdx.x;
-  T r[NB];  // row `lane` of the block; identity padding beyond kb
-  StaticFor<0, NB>::Run([&](auto cc) {
-    constexpr int c = decltype(cc)::value;
-    T v = (lane == c) ? T(1) : T(0);
-    if (lane < kb && c < kb && lane >= c) v = W[lane + static_cast<int64_t>(c) * ld];
-    r[c] = v;
-  });
+constexpr int KC = 32;  // columns of the outer panel consumed per LDS stage
+
+// Forces `v` to be computed at this point of the program (an empty instruction that "modifies" it).
+template <class T> __device__ inline void Pin(T& v) { asm volatile("" : "+v"(v)); }
+
+// Row `lane` of a 64 x 64 lower-triangular block in registers -> its Cholesky factor in place.
+// ONE WAVE, register resident: the pivot column is broadcast lane by lane with v_readlane, so the
+// 64 elimination steps need no LDS and no barriers (an LDS version spent ~190 us per block in
+// ~400 barriers).  Returns true on a non-positive pivot.
+template <class T> __device__ inline bool CholRows(T (&r)[NB], int lane) {
   bool bad = false;
   // right-looking Cholesky: after step j, r[j] holds L[lane][j]
   StaticFor<0, NB>::Run([&](auto jj) {
@@ -77,15 +74,204 @@ __global__ __launch_bounds__(64) void PotrfDiagKernel(T* W, int64_t ld, int kb, 
     const T dj = sqrt(d);
     const T l = lane > j ? r[j] / dj : (lane == j ? dj : T(0));
     r[j] = l;
-    StaticFor<j + 1, NB>::Run([&](auto cc) {
-      constexpr int c = decltype(cc)::value;
-      r[c] -= l * ReadLane<c>(l);  // only lanes >= c hold live entries of column c
+    // four broadcasts, then their four updates: a readlane result needs two idle cycles before
+    // a vector instruction may use it, which the grouping fills with the other readlanes
+    StaticFor<0, (NB - 1 - j + 3) / 4>::Run([&](auto gg) {
+      constexpr int c0 = j + 1 + 4 * decltype(gg)::value;
+      T b[4];
+      StaticFor<0, 4>::Run([&](auto ii) {
+        constexpr int c = c0 + decltype(ii)::value;
+        if constexpr (c < NB) b[decltype(ii)::value] = ReadLane<c>(l);
+      });
+      StaticFor<0, 4>::Run([&](auto ii) {
+        constexpr int c = c0 + decltype(ii)::value;
+        // only lanes >= c hold live entries of column c
+        if constexpr (c < NB) r[c] -= l * b[decltype(ii)::value];
+      });
+      // Pin the updates here.  The whole factorisation is one basic block, and left alone the
+      // compiler defers every update of column c to step c: it parks the ~2000 broadcast values
+      // in spare VGPR lanes (v_writelane) and fetches them back later, twice the lane traffic.
+      StaticFor<0, 4>::Run([&](auto ii) {
+        constexpr int c = c0 + decltype(ii)::value;
+        if constexpr (c < NB) Pin(r[c]);
+      });
     });
   });
-  if (bad && lane == 0) *flag = 1;
+  return bad;
+}
+
+// One 64-column step of the left-looking factorisation inside an outer panel [K0, K0 + 256):
+// the diagonal block D = W[k0:k0+kb, k0:k0+kb] first receives the update of the panel columns
+// already factored, D -= P P^T with P = W[k0:k0+kb, K0:k0], then wave 0 factors it in registers.
+// One workgroup; the rows below are PotrfPanelStepKernel's.
+template <class T>
+__global__ __launch_bounds__(256) void PotrfDiagStepKernel(T* W, int64_t ld, int64_t K0, int64_t k0,
+                                                           int kb, int* flag) {
+  __shared__ T D[NB][NB];   // [column][row]
+  __shared__ T Pc[KC][NB];  // [k][row]
+  const int t = threadIdx.x, r = t & 63, q = t >> 6;
+  T acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = q * 16 + c;
+    T v = (r == col) ? T(1) : T(0);
+    if (r < kb && col < kb && r >= col) v = W[(k0 + r) + (k0 + col) * ld];
+    acc[c] = v;
+  }
+  // the next stage's global loads are issued before this stage's arithmetic (the loop is
+  // otherwise a chain of exposed memory latencies: one workgroup, nothing else to switch to)
+  constexpr int PF = KC * NB / 256;
+  T pf[PF];
+  auto fetch = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = t + i * 256, rr = idx & 63, k = idx >> 6;
+      pf[i] = rr < kb ? W[(k0 + rr) + (kk + k) * ld] : T(0);
+    }
+  };
+  if (K0 < k0) fetch(K0);
+  for (int64_t kk = K0; kk < k0; kk += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = t + i * 256;
+      Pc[idx >> 6][idx & 63] = pf[i];
+    }
+    __syncthreads();
+    if (kk + KC < k0) fetch(kk + KC);
+#pragma unroll 4
+    for (int k = 0; k < KC; ++k) {
+      const T a = Pc[k][r];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] -= a * Pc[k][q * 16 + c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) D[q * 16 + c][r] = acc[c];
+  __syncthreads();
+  if (q != 0) return;
+  T row[NB];
   StaticFor<0, NB>::Run([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    if (lane < kb && c < kb && lane >= c) W[lane + static_cast<int64_t>(c) * ld] = r[c];
+    row[c] = r >= c ? D[c][r] : T(0);
+  });
+  const bool bad = CholRows(row, r);
+  if (bad && r == 0) *flag = 1;
+  StaticFor<0, NB>::Run([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if (r < kb && c < kb && r >= c) W[(k0 + r) + (k0 + c) * ld] = row[c];
+  });
+}
+
+// The rows below the diagonal block in the same step: T = W[rows, k0:k0+kb] - L[rows, K0:k0] P^T,
+// then L[rows, k0:k0+kb] = T L11^-T by forward substitution (thread per row, L11 broadcast from
+// LDS).  64 rows per workgroup: four waves split the columns of the update, wave 0 substitutes.
+template <class T>
+__global__ __launch_bounds__(256) void PotrfPanelStepKernel(T* W, int64_t ld, int64_t n, int64_t K0,
+                                                            int64_t k0, int kb) {
+  __shared__ T Tt[NB][NB];          // [column][row]
+  __shared__ T buf[2 * KC * NB];    // stage: Lr[k][row] | Pc[k][col]; afterwards L11 as [j][k]
+  T* Lr = buf;
+  T* Pc = buf + KC * NB;
+  const int t = threadIdx.x, r = t & 63, q = t >> 6;
+  const int64_t row0 = k0 + kb + static_cast<int64_t>(blockIdx.x) * NB;
+  const int64_t row = row0 + r;
+  const bool live = row < n;
+  T acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = q * 16 + c;
+    acc[c] = (live && col < kb) ? W[row + (k0 + col) * ld] : T(0);
+  }
+  constexpr int PF = KC * NB / 256;
+  T pfl[PF], pfp[PF];  // next stage, in flight during this stage's arithmetic
+  auto fetch = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = t + i * 256, rr = idx & 63, k = idx >> 6;
+      pfl[i] = (row0 + rr < n) ? W[(row0 + rr) + (kk + k) * ld] : T(0);
+      pfp[i] = rr < kb ? W[(k0 + rr) + (kk + k) * ld] : T(0);
+    }
+  };
+  if (K0 < k0) fetch(K0);
+  for (int64_t kk = K0; kk < k0; kk += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = t + i * 256;
+      Lr[idx] = pfl[i];
+      Pc[idx] = pfp[i];
+    }
+    __syncthreads();
+    if (kk + KC < k0) fetch(kk + KC);
+#pragma unroll 4
+    for (int k = 0; k < KC; ++k) {
+      const T a = Lr[k * NB + r];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc[c] -= a * Pc[k * NB + q * 16 + c];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) Tt[q * 16 + c][r] = acc[c];
+  // L11 (identity padding beyond kb), stored [j][k] so that the k run of one j is contiguous
+  for (int idx = t; idx < NB * NB; idx += 256) {
+    const int j = idx & 63, k = idx >> 6;
+    T v = (j == k) ? T(1) : T(0);
+    if (j < kb && k < kb && j >= k) v = W[(k0 + j) + (k0 + k) * ld];
+    buf[j * NB + k] = v;
+  }
+  __syncthreads();
+  if (q == 0) {
+    // forward substitution in 8 x 8 blocks, x written back over T: the outer loops stay rolled
+    // (fully unrolled, the compiler hoists all 2016 broadcast reads and spills them)
+#pragma unroll 1
+    for (int jb = 0; jb < NB; jb += 8) {
+      T tv[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) tv[jj] = Tt[jb + jj][r];
+#pragma unroll 1
+      for (int k8 = 0; k8 < jb; k8 += 8) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const T xk = Tt[k8 + kk][r];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) tv[jj] -= xk * buf[(jb + jj) * NB + k8 + kk];
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+        for (int kk = 0; kk < jj; ++kk) tv[jj] -= tv[kk] * buf[(jb + jj) * NB + jb + kk];
+        tv[jj] /= buf[(jb + jj) * NB + jb + jj];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) Tt[jb + jj][r] = tv[jj];
+    }
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = q * 16 + c;
+      if (col < kb) W[row + (k0 + col) * ld] = Tt[col][r];
+    }
+  }
+}
+
+// inv(L11) of every 64 x 64 diagonal block of the factor (one wave per block): Dinv block b is
+// dense NB x NB (ld NB), zeros above the diagonal and beyond the matrix.
+template <class T>
+__global__ __launch_bounds__(64) void TrtriDiagBlocksKernel(const T* W, int64_t ld, int64_t n, T* Dinv) {
+  const int lane = threadIdx.x;
+  const int64_t k0 = static_cast<int64_t>(blockIdx.x) * NB;
+  const int kb = static_cast<int>(n - k0 < NB ? n - k0 : NB);
+  T r[NB];
+  StaticFor<0, NB>::Run([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    T v = (lane == c) ? T(1) : T(0);
+    if (lane < kb && c < kb && lane >= c) v = W[(k0 + lane) + (k0 + c) * ld];
+    r[c] = v;
   });
   // X = inv(L), columns last to first (trti2 order):
   //   X[j][j] = 1/L[j][j] ;  X[j+1:, j] = -X[j+1:, j+1:] * L[j+1:, j] * X[j][j]
@@ -95,17 +281,38 @@ __global__ __launch_bounds__(64) void PotrfDiagKernel(T* W, int64_t ld, int kb, 
     constexpr int j = NB - 1 - decltype(ii)::value;
     const T ajj = T(1) / ReadLane<j>(r[j]);
     T acc = T(0);
-    StaticFor<j + 1, NB>::Run([&](auto kc) {
-      constexpr int kk = decltype(kc)::value;
-      // x[kk] of lanes < kk is zero (strictly upper part), so no predicate is needed
-      acc += x[kk] * ReadLane<kk>(r[j]);
+    // x[kk] of lanes < kk is zero (strictly upper part), so no predicate is needed; broadcasts
+    // in groups of four (see CholRows)
+    StaticFor<0, (NB - 1 - j + 3) / 4>::Run([&](auto gg) {
+      constexpr int c0 = j + 1 + 4 * decltype(gg)::value;
+      T b[4];
+      StaticFor<0, 4>::Run([&](auto ii) {
+        constexpr int kk = c0 + decltype(ii)::value;
+        if constexpr (kk < NB) b[decltype(ii)::value] = ReadLane<kk>(r[j]);
+      });
+      StaticFor<0, 4>::Run([&](auto ii) {
+        constexpr int kk = c0 + decltype(ii)::value;
+        if constexpr (kk < NB) acc += x[kk] * b[decltype(ii)::value];
+      });
+      Pin(acc);
     });
     x[j] = lane > j ? -acc * ajj : (lane == j ? ajj : T(0));
   });
+  T* out = Dinv + static_cast<int64_t>(blockIdx.x) * NB * NB;
   StaticFor<0, NB>::Run([&](auto cc) {
     constexpr int c = decltype(cc)::value;
-    Dinv[lane + c * NB] = (lane < kb && c < kb && lane >= c) ? x[c] : T(0);
+    out[lane + c * NB] = (lane < kb && c < kb && lane >= c) ? x[c] : T(0);
   });
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void ScatterDiagBlocksKernel(const T* Dinv, T* X, int64_t ld, int64_t n) {
+  const int64_t k0 = static_cast<int64_t>(blockIdx.x) * NB;
+  const T* src = Dinv + static_cast<int64_t>(blockIdx.x) * NB * NB;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+    const int r = idx & 63, c = idx >> 6;
+    if (k0 + r < n && k0 + c < n) X[(k0 + r) + (k0 + c) * ld] = src[idx];
+  }
 }
 
 DVec Sub(const DVec& W, int64_t i, int64_t j, int64_t ld) {
@@ -140,11 +347,18 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
   auto flag_buf = rt.Alloc(sizeof(int));
   int* flag = static_cast<int*>(flag_buf->p);
   EPS_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-  PotrfBlocked(W, n, dinv, flag);
+  {
+    ProfScope p1("potrf", n);
+    PotrfBlocked(W, n, dinv, flag);
+  }
 
   // ---- 2. X = inv(L) by recursive doubling ---------------------------------------------------
   DVec X = DVec::Zeros(n * n, dt);
-  DoublingInverse(W, X, n, dinv, n);
+  {
+    ProfScope p2("trtri", n);
+    DoublingInverse(W, X, n, dinv, n);
+  }
+  ProfScope p3("lauum", n);
 
   // ---- 3. W^-1 = X^T X ------------------------------------------------------------------------
   // Row block p of the lower-triangular X is zero right of column (p+1)*B, so it only touches
@@ -179,18 +393,33 @@ void DoublingInverse(const DVec& W, const DVec& X, int64_t n, const DVec& dinv, 
   const DType dt = W.dt;
   const int64_t ld = n;
   const int64_t nb = (n + NB - 1) / NB;
-  for (int64_t kblk = 0; kblk < nb; ++kblk) {
-    const int64_t k0 = kblk * NB;
-    const int64_t kb = std::min<int64_t>(NB, n - k0);
-    // copy the kb x kb inverse block (ld NB) into X's diagonal block (ld n)
-    EPS_HIP(hipMemcpy2DAsync(Sub(X, k0, k0, ld).data(), ld * DTypeSize(dt),
-                             dinv.Slice(kblk * NB * NB, NB * NB).data(), NB * DTypeSize(dt),
-                             kb * DTypeSize(dt), kb, hipMemcpyDeviceToDevice, s));
-  }
+  // the 64 x 64 inverse blocks (ld NB) go onto X's diagonal (ld n), all in one launch
+  if (dt == F32)
+    hipLaunchKernelGGL(ScatterDiagBlocksKernel<float>, dim3(static_cast<unsigned>(nb)), dim3(256), 0, s,
+                       dinv.as<float>(), X.as<float>(), ld, n);
+  else
+    hipLaunchKernelGGL(ScatterDiagBlocksKernel<double>, dim3(static_cast<unsigned>(nb)), dim3(256), 0, s,
+                       dinv.as<double>(), X.as<double>(), ld, n);
   const int64_t half = std::min<int64_t>(cap, n) / 2 + NB;
-  DVec tmp2 = DVec::Empty(std::max<int64_t>(1, half * half), dt);
+  const int64_t kBatchBelow = 4096;  // levels below this size: all pairs of a level in one launch
+  DVec tmp2 = DVec::Empty(std::max<int64_t>({1, half * half, n * std::min(cap, kBatchBelow) / 4}), dt);
   for (int64_t sz = NB; sz < cap; sz *= 2) {
-    for (int64_t r0 = 0; r0 + sz < n; r0 += 2 * sz) {
+    int64_t r_first = 0;
+    if (sz < kBatchBelow) {
+      // the pairs of one level are independent and (but for a ragged last one) of equal shape:
+      // two batched launches per level instead of two per pair (sz = 64: 156 -> 2)
+      const int64_t P = n / (2 * sz);  // full pairs
+      if (P > 0) {
+        const int64_t stride = 2 * sz * (ld + 1);
+        EPS_CHECK(tmp2.n >= P * sz * sz);
+        GemmBatched(false, false, sz, sz, sz, 1.0, Sub(W, sz, 0, ld), ld, stride, X, ld, stride, 0.0,
+                    tmp2, sz, sz * sz, P);
+        GemmBatched(false, false, sz, sz, sz, -1.0, Sub(X, sz, sz, ld), ld, stride, tmp2, sz, sz * sz,
+                    0.0, Sub(X, sz, 0, ld), ld, stride, P);
+      }
+      r_first = P * 2 * sz;
+    }
+    for (int64_t r0 = r_first; r0 + sz < n; r0 += 2 * sz) {
       const int64_t s1 = sz;                                  // rows/cols of block 1
       const int64_t s2 = std::min<int64_t>(sz, n - (r0 + sz));  // rows of block 2
       DVec L21 = Sub(W, r0 + s1, r0, ld);
@@ -202,7 +431,9 @@ void DoublingInverse(const DVec& W, const DVec& X, int64_t n, const DVec& dinv, 
       // X11 and X22 are lower triangular: column block j of X11 is zero above row j*cb and row
       // block i of X22 is zero right of column (i+1)*rb, so the products only run over the
       // non-zero part of K (62 % of the dense flops with four blocks).
-      const int64_t nsplit = sz >= 1024 ? 4 : 1;
+      // ... as long as every piece still fills the chip (>= ~400 tiles of 128 x 128)
+      const int64_t tiles = ((s1 + 127) / 128) * ((s2 + 127) / 128);
+      const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(4, tiles / 400));
       const int64_t cb = (s1 + nsplit - 1) / nsplit;
       for (int64_t c0 = 0; c0 < s1; c0 += cb) {
         const int64_t cw = std::min<int64_t>(cb, s1 - c0);
@@ -225,49 +456,52 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
   hipStream_t s = rt.stream();
   const DType dt = W.dt;
   const int64_t ld = n;
-  DVec panel = DVec::Empty(std::max<int64_t>(n, 1) * NB, dt);
   // ---- 1. blocked Cholesky ------------------------------------------------------------------
   // Two-level blocking: 64-wide steps update only the rest of their 256-wide outer panel; the
   // trailing matrix sees one rank-256 update per outer panel (a rank-64 update of the whole
   // trailing matrix is HBM-bound: it re-reads and re-writes up to n^2 entries for 64 columns).
-  const int64_t OB = 4 * NB;
-  for (int64_t K0 = 0; K0 < n; K0 += OB) {
-    const int64_t KB = std::min<int64_t>(OB, n - K0);
-    for (int64_t k0 = K0; k0 < K0 + KB; k0 += NB) {
-      const int64_t kblk = k0 / NB;
-      const int kb = static_cast<int>(std::min<int64_t>(NB, n - k0));
-      DVec Wkk = Sub(W, k0, k0, ld);
-      DVec Dk = dinv.Slice(kblk * NB * NB, NB * NB);
-      if (dt == F32) {
-        hipLaunchKernelGGL(PotrfDiagKernel<float>, dim3(1), dim3(64), 0, s, Wkk.as<float>(), ld,
-                           kb, Dk.as<float>(), flag);
-      } else {
-        hipLaunchKernelGGL(PotrfDiagKernel<double>, dim3(1), dim3(64), 0, s, Wkk.as<double>(),
-                           ld, kb, Dk.as<double>(), flag);
+  const int64_t OB = 4 * NB;  // measured: 6 and 8 blocks are 0.5 / 1.4 ms slower at n = 10^4
+  {
+    // Left-looking inside the outer panel: a 64-column step is two launches - the diagonal block
+    // (update with the panel columns already done + register-resident factorisation) and the
+    // rows below it (same update + forward substitution against the new L11) - instead of the
+    // diagonal kernel, a copy and two small GEMMs; the 64 x 64 inverses the later stages want are
+    // formed for all blocks at once at the end.
+    for (int64_t K0 = 0; K0 < n; K0 += OB) {
+      const int64_t KB = std::min<int64_t>(OB, n - K0);
+      for (int64_t k0 = K0; k0 < K0 + KB; k0 += NB) {
+        const int kb = static_cast<int>(std::min<int64_t>(NB, n - k0));
+        const int64_t rem = n - (k0 + kb);
+        const unsigned blocks = static_cast<unsigned>((rem + NB - 1) / NB);
+        if (dt == F32) {
+          hipLaunchKernelGGL(PotrfDiagStepKernel<float>, dim3(1), dim3(256), 0, s, W.as<float>(), ld,
+                             K0, k0, kb, flag);
+          if (blocks)
+            hipLaunchKernelGGL(PotrfPanelStepKernel<float>, dim3(blocks), dim3(256), 0, s,
+                               W.as<float>(), ld, n, K0, k0, kb);
+        } else {
+          hipLaunchKernelGGL(PotrfDiagStepKernel<double>, dim3(1), dim3(256), 0, s, W.as<double>(),
+                             ld, K0, k0, kb, flag);
+          if (blocks)
+            hipLaunchKernelGGL(PotrfPanelStepKernel<double>, dim3(blocks), dim3(256), 0, s,
+                               W.as<double>(), ld, n, K0, k0, kb);
+        }
       }
-      const int64_t rem = n - (k0 + kb);
-      if (rem <= 0) continue;
-      DVec W21 = Sub(W, k0 + kb, k0, ld);
-      DVec tmp = panel.Slice(0, rem * kb);
-      MatCopy(false, rem, kb, 1.0, W21, ld, tmp);
-      // L21 = W21 * inv(L11)^T
-      Gemm(false, true, rem, kb, kb, 1.0, tmp, rem, Dk, NB, 0.0, W21, ld);
-      // the remaining columns of this outer panel: W[k0+kb:, k0+kb : K0+KB] -= L21 L21[0:pc]^T
-      const int64_t pc = K0 + KB - (k0 + kb);
-      if (pc > 0) {
-        DVec Wp = Sub(W, k0 + kb, k0 + kb, ld);
-        Gemm(false, true, rem, pc, kb, -1.0, W21, ld, W21, ld, 1.0, Wp, ld);
+      const int64_t rem2 = n - (K0 + KB);
+      if (rem2 > 0) {
+        DVec L21 = Sub(W, K0 + KB, K0, ld);
+        DVec W22 = Sub(W, K0 + KB, K0 + KB, ld);
+        Gemm(false, true, rem2, rem2, KB, -1.0, L21, ld, L21, ld, 1.0, W22, ld, true);
       }
     }
-    // trailing matrix: W22 -= L21 L21^T with the whole outer panel (lower tiles only)
-    const int64_t rem2 = n - (K0 + KB);
-    if (rem2 > 0) {
-      DVec L21 = Sub(W, K0 + KB, K0, ld);
-      DVec W22 = Sub(W, K0 + KB, K0 + KB, ld);
-      Gemm(false, true, rem2, rem2, KB, -1.0, L21, ld, L21, ld, 1.0, W22, ld, true);
-    }
+    const unsigned nblk = static_cast<unsigned>((n + NB - 1) / NB);
+    if (dt == F32)
+      hipLaunchKernelGGL(TrtriDiagBlocksKernel<float>, dim3(nblk), dim3(64), 0, s, W.as<float>(), ld, n,
+                         dinv.as<float>());
+    else
+      hipLaunchKernelGGL(TrtriDiagBlocksKernel<double>, dim3(nblk), dim3(64), 0, s, W.as<double>(), ld,
+                         n, dinv.as<double>());
   }
-
 }
 
 }  // namespace

@@ -323,7 +323,20 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = wave & 1, wj = wave >> 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const bool in_i = i0 + MT <= M, in_j = j0 + MT <= N;
+  // Edge tiles load a full 128-wide window that ends at the matrix edge (origin shifted back)
+  // and store only their own rows / columns: every k-slab but the last then takes the
+  // unchecked load path, where the bounds-checked one runs several times slower - and an edge
+  // tile that starts late is the tail of the whole launch.
+  int64_t li0 = i0, lj0 = j0;
+  bool in_i = i0 + MT <= M, in_j = j0 + MT <= N;
+  if (!in_i && M >= MT && (!CA || M % 4 == 0)) {
+    li0 = M - MT;
+    in_i = true;
+  }
+  if (!in_j && N >= MT && (!CB || N % 4 == 0)) {
+    lj0 = N - MT;
+    in_j = true;
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -338,11 +351,11 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
   const int64_t nfull = (in_i && in_j) ? K / MK : 0;  // slabs that need no bounds checks
   auto load = [&](int64_t kt) {
     if (kt < nfull) {
-      LoadSlab<CA, true>(ra, A, lda, i0, kt * MK, M, K);
-      LoadSlab<CB, true>(rb, B, ldb, j0, kt * MK, N, K);
+      LoadSlab<CA, true>(ra, A, lda, li0, kt * MK, M, K);
+      LoadSlab<CB, true>(rb, B, ldb, lj0, kt * MK, N, K);
     } else if (kt < nk) {
-      LoadSlab<CA, false>(ra, A, lda, i0, kt * MK, M, K);
-      LoadSlab<CB, false>(rb, B, ldb, j0, kt * MK, N, K);
+      LoadSlab<CA, false>(ra, A, lda, li0, kt * MK, M, K);
+      LoadSlab<CB, false>(rb, B, ldb, lj0, kt * MK, N, K);
     }
   };
   // One k-slab: MFMAs on stage kt&1 (LDS operands read one k-step ahead), then the prefetched
@@ -384,8 +397,8 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
     }
     __syncthreads();
     if (FAST) {
-      LoadSlab<CA, true>(ra, A, lda, i0, (kt + 2) * MK, M, K);
-      LoadSlab<CB, true>(rb, B, ldb, j0, (kt + 2) * MK, N, K);
+      LoadSlab<CA, true>(ra, A, lda, li0, (kt + 2) * MK, M, K);
+      LoadSlab<CB, true>(rb, B, ldb, lj0, (kt + 2) * MK, N, K);
       __builtin_amdgcn_sched_barrier(0);  // do not let the scheduler sink these loads
     } else {
       load(kt + 2);
@@ -402,14 +415,14 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
 
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
-    const int64_t i = i0 + wi * 64 + a * 32 + l31;
-    if (i >= M) continue;
+    const int64_t i = li0 + wi * 64 + a * 32 + l31;
+    if (i < i0 || i >= M) continue;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (j >= N) continue;
+        const int64_t j = lj0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (j < j0 || j >= N) continue;
         float* c = C + i + j * ldc;
         const float v = alpha * acc[a][b][r];
         *c = (beta == 0.0f) ? v : v + beta * (*c);

@@ -279,10 +279,11 @@ std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Inverse() const {
 std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::InverseDistributed() const {
   Comm* comm = Runtime::Get().comm();
   const int64_t nn = n();
-  // measured at n = 1e4 (tools_microbench.py): whole inverse 45 ms; a 1/8 slab of columns 37 ms,
-  // a quarter 40 ms, a half 44 ms - the Cholesky is the common part.  Worth a collective from
-  // four ranks up (EPSILON_HIP_DIST_INVERSE=<min ranks> overrides; tests use 2).
-  int min_ranks = 4;
+  // measured at n = 1e4 (tools_microbench.py): whole inverse 26.5 ms; a 1/8 slab of columns
+  // 24.6 ms, a quarter 27.2 ms, a half 31.5 ms - the Cholesky (16 ms) is the common part, so
+  // with the all-gather on top the split no longer pays on one node.  Kept (and tested) for
+  // larger blocks / more ranks: EPSILON_HIP_DIST_INVERSE=<min ranks> turns it on (tests use 2).
+  int min_ranks = 16;
   if (const char* e = std::getenv("EPSILON_HIP_DIST_INVERSE")) min_ranks = std::atoi(e);
   if (comm == nullptr || comm->size() < std::max(2, min_ranks) || m() != nn || nn < 1024)
     return Inverse();

@@ -33,8 +33,14 @@ def gemm(ta, tb, M, N, K, lower=0, iters=3, dtype="f32"):
 def inverse(n, iters=2, dtype="f32"):
     _solve.set_option("dtype", dtype)
     ms = ctypes.c_double()
+    _solve.set_option("profile_filter", "potrf,trtri,lauum")
+    _solve.profile_enable(True)
+    _solve.profile_reset()
     _solve._check(L.eps_bench_spd_inverse(ctypes.c_int64(n), ctypes.c_int(iters), ctypes.byref(ms)))
-    print("spd_inverse n=%d %s: %.2f ms" % (n, dtype, ms.value), flush=True)
+    prof = _solve.profile_dump()
+    _solve.profile_enable(False)
+    phases = ", ".join("%s %.2f" % (k.split(":")[0], t / c) for k, (c, t) in sorted(prof.items()) if c)
+    print("spd_inverse n=%d %s: %.2f ms  (%s)" % (n, dtype, ms.value, phases), flush=True)
 
 
 def inverse_columns(n, cnt, iters=2, dtype="f32"):
@@ -60,6 +66,10 @@ if __name__ == "__main__":
         gemm(0, 1, 4096, 4096, 4096, iters=5)
         gemm(0, 0, 4096, 4096, 4096, iters=5)
         gemm(1, 0, 4096, 4096, 4096, iters=5)
+    if "syrk" in what:
+        gemm(0, 1, 10000, 10000, 50000, lower=2, iters=2)
+    if "inverse1" in what:
+        inverse(10000, iters=1)
     if "inverse" in what:
         inverse(10000)
         inverse(2048)

@@ -51,7 +51,9 @@ def main():
                 for nm, (cnt, av, mn, mx) in sorted(counters[k].items()):
                     w.writerow([k, nm, cnt, "%.2f" % av, "%.2f" % mn, "%.2f" % mx])
     fused = [k for k in counters if "LassoFused" in k and "FETCH_SIZE" in counters[k]]
-    fused.sort(key=lambda k: -counters[k]["FETCH_SIZE"][0])
+    # the bench's untimed process warm-up runs a small instance of the same kernel template:
+    # the judged launches are the ones that read the full-size matrix
+    fused.sort(key=lambda k: -counters[k]["FETCH_SIZE"][1])
     fk = fused[0]
     fetch, write = counters[fk]["FETCH_SIZE"][1], counters[fk]["WRITE_SIZE"][1]
     bench = json.loads(open(os.path.join(OUT, "bench_default.json")).read().strip().splitlines()[-1])
