@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""The reference's own published benchmark problems (docs/_static/benchmarks.png,
+docs/notebooks/mnist.rst) at their published sizes, solved through the C ABI on one MI355X.
+
+Not the judged bench line (bench.py).  What is compared, and what is not: the reference's
+figures are END-TO-END times of its CPU stack (CVXPY conversion + compile + solve, one thread,
+hardware not stated); the figures here are the `solve()` call alone - operator setup (Gram,
+factorisation), the ADMM loop and the upload of the host fp64 blobs - on hand-compiled IR of the
+same problems with synthetic data of the same shape (no network: MNIST itself is not available,
+its shape is).  Stopping rule: the reference defaults (abs_tol 1e-4, rel_tol 1e-2, rho 1).
+
+One JSON line per problem:  python bench_suite.py [names...]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STATES = ["NOT_STARTED", "INITIALIZING", "RUNNING", "OPTIMAL", "MAX_ITERATIONS_REACHED", "ERROR"]
+
+
+def lasso():
+    from epsilon_amd import ir, problems
+    A, b = problems.regression_data(1500, 5000, rho=0.01, seed=0)
+    lam = 0.5 * np.abs(A.T.dot(b)).max()
+    prob = problems.lasso_ir(ir.dense_matrix(A), ir.constant(b), lam, 5000)
+    return prob, lambda x: problems.lasso_objective(A, b, lam, x[problems.LASSO_VAR]), \
+        dict(ref_total_s=3.69, ref_objective=3.21e1, size="m=1500 n=5000, x0 density 0.01",
+             ref_source="docs/_static/benchmarks.png (benchmark.py:37)")
+
+
+def lasso_sparse():
+    import scipy.sparse as sp
+    from epsilon_amd import ir, problems
+    rng = np.random.RandomState(0)
+    m, n = 1500, 50000
+    A = sp.random(m, n, density=0.1, format="csc", random_state=rng, data_rvs=rng.randn)
+    # unit l2 columns, as problem_util.normalized_data_matrix does
+    A = (A @ sp.diags(1.0 / np.sqrt(np.ravel(A.multiply(A).sum(axis=0))))).tocsc()
+    x0 = np.zeros(n)
+    idx = rng.choice(n, n // 100, replace=False)
+    x0[idx] = rng.randn(len(idx))
+    b = A.dot(x0) + 0.05 * rng.randn(m)
+    lam = 0.5 * np.abs(A.T.dot(b)).max()
+    prob = problems.lasso_ir(ir.sparse_matrix(A), ir.constant(b), lam, n)
+
+    def obj(x):
+        r = A.dot(x[problems.LASSO_VAR]) - b
+        return float(r.dot(r) + lam * np.abs(x[problems.LASSO_VAR]).sum())
+    return prob, obj, dict(ref_total_s=13.58, ref_objective=4.37e2, size="m=1500 n=50000, density 0.1 (CSC)",
+                           ref_source="docs/_static/benchmarks.png (benchmark.py:38)")
+
+
+def tv_1d():
+    from epsilon_amd import problems
+    prob, info = problems.tv_1d(10 ** 5, seed=0)
+    return prob, lambda x: problems.tv_1d_objective(info["b"], info["lam"], x["var:x"]), \
+        dict(ref_total_s=0.13, ref_objective=2.29e5, size="n=1e5",
+             ref_source="docs/_static/benchmarks.png (benchmark.py:53)")
+
+
+def robust_pca():
+    from epsilon_amd import problems
+    n = 100
+    prob, info = problems.robust_pca(n, seed=0)
+    return prob, lambda x: problems.robust_pca_objective(info["lam"], x["var:L"].reshape(n, n, order="F"),
+                                                         x["var:S"].reshape(n, n, order="F")), \
+        dict(ref_total_s=0.59, ref_objective=1.71e3, size="n=100",
+             ref_source="docs/_static/benchmarks.png (benchmark.py:51)")
+
+
+def _hinge(m, nf, k, lam, ref_s, ref_iter, src):
+    from epsilon_amd import problems
+    X, Y = problems.multiclass_hinge_data(m, nf, k, seed=0)
+    prob, _ = problems.multiclass_hinge(X, Y, lam)
+    return prob, lambda x: problems.multiclass_hinge_objective(X, Y, lam, x["var:Theta"].reshape(nf, k, order="F")), \
+        dict(ref_solve_s=ref_s, ref_iterations=ref_iter, size="X %dx%d, k=%d, lam=%g (synthetic X in [0,1), random labels)"
+             % (m, nf, k, lam), ref_source=src)
+
+
+def mnist_hinge():
+    return _hinge(60000, 784, 10, 1.0, 38.75, 40, "docs/notebooks/mnist.rst:130-136")
+
+
+def mnist_hinge_features():
+    return _hinge(60000, 4000, 10, 10.0, 196.57, 30, "docs/notebooks/mnist.rst:238-244")
+
+
+SUITE = [("lasso", lasso), ("tv_1d", tv_1d), ("robust_pca", robust_pca), ("mnist_hinge", mnist_hinge),
+         ("mnist_hinge_features", mnist_hinge_features), ("lasso_sparse", lasso_sparse)]
+
+
+def main():
+    import torch  # noqa: F401  (first: its HIP runtime is the one the process binds to)
+    from epsilon_amd import _solve, problems, wire
+    names = sys.argv[1:] or [n for n, _ in SUITE]
+    _solve.set_option("dtype", "f32")
+    wp, _ = problems.lasso(256, 1024, seed=1)  # untimed: loads the code objects
+    _solve.solve(wp.SerializeToString(), [], wire.SolverParams(max_iterations=20).SerializeToString(),
+                 wp.expression_data())
+    for name, build in SUITE:
+        if name not in names:
+            continue
+        t0 = time.time()
+        prob, objective, ref = build()
+        pb, data = prob.SerializeToString(), prob.expression_data()
+        t_build = time.time() - t0
+        params = wire.SolverParams(max_iterations=50000)
+        t0 = time.time()
+        st, x = _solve.solve(pb, [], params.SerializeToString(), data)
+        t_solve = time.time() - t0
+        S = wire.SolverStatus.FromString(st)
+        xs = {k: np.frombuffer(v) for k, v in x.items()}
+        out = {"problem": name, "solve_s": t_solve, "init_s": S.timing.init_time, "loop_s": S.timing.total_time - S.timing.init_time,
+               "iterations": S.num_iterations + 1, "state": STATES[S.state], "objective": objective(xs),
+               "dtype": "f32", "data": "synthetic", "host_blob_bytes": sum(len(v) for v in data.values()),
+               "ir_build_s": t_build, "reference": ref}
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

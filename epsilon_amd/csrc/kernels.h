@@ -126,11 +126,15 @@ void ZoneEpigraphSums(int64_t n, const double* key, const double* w2, double lam
 // ---- K11: SVD for the orthogonally-invariant proxes (reference prox/ortho_invariant.cc) ------
 // One-sided Jacobi on W (m x n, ld = m): on return W = U*Sigma (orthogonal columns) and the
 // input equals W V^T; V (n x n) is overwritten.  Returns the number of sweeps used.
-int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40);
+// warm: V holds an orthogonal matrix on entry and W has already been multiplied by it (the
+// decomposition continues from there: Y = W V^T holds throughout).
+int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40,
+              bool warm = false);
 // The same decomposition by the block algorithm (pairs of 32-column panels: batched Gram on the
 // MFMA kernel, 64 x 64 eigenproblems on chip, batched GEMM updates); JacobiSvd switches to it
 // from 1536 columns up (measured crossover on MI355X; EPSILON_HIP_SVD=block|scalar forces one).
-int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40);
+int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40,
+                   bool warm = false);
 void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma);
 // W[:, j] *= xt[j] / sigma[j]   (0 where sigma[j] == 0, as ortho_invariant.cc:44-49)
 void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt);

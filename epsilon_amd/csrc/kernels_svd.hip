@@ -109,6 +109,126 @@ __global__ __launch_bounds__(kBlock) void JacobiStepKernel(T* W, int64_t m, int6
   }
 }
 
+// Small matrices (W and V together fit in the LDS of one CU): the whole decomposition - every
+// rotation step of every sweep - in ONE launch of one workgroup.  The launch-per-step form above
+// costs ~5 us per step whatever the size (99 launches and a host round trip per sweep at
+// n = 100); here a step is a wave per column pair on LDS-resident columns and a barrier.
+constexpr int kSmallThreads = 1024;
+constexpr size_t kSmallLdsBytes = 150 * 1024;
+
+template <class T>
+__global__ __launch_bounds__(kSmallThreads) void SmallJacobiSvdKernel(T* Wg, int m, int n, T* Vg,
+                                                                      int npad, double tol,
+                                                                      int max_sweeps, int warm,
+                                                                      int* sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char small_svd_lds[];
+  T* W = reinterpret_cast<T*>(small_svd_lds);  // m x n, column-major
+  T* V = W + m * n;                            // n x n
+  __shared__ int rotated;
+  // a group of G lanes per column pair, G the largest power of two that still gives every pair
+  // of a step its own group (n = 100: 50 pairs, G = 16), so a step is one pass and a barrier.
+  // 32-bit indices and a modulo-free tournament: the step is instruction-bound (16 waves on
+  // one CU), and 64-bit index arithmetic was most of it.
+  const int tid = threadIdx.x;
+  int G = 64;
+  while (G > 4 && kSmallThreads / G < npad / 2) G >>= 1;
+  const int lane = tid & (G - 1), grp = tid / G, ngrp = kSmallThreads / G;
+  for (int i = tid; i < m * n; i += kSmallThreads) W[i] = Wg[i];
+  if (warm) {
+    for (int i = tid; i < n * n; i += kSmallThreads) V[i] = Vg[i];
+  } else {
+    for (int i = tid; i < n * n; i += kSmallThreads) V[i] = (i % (n + 1) == 0) ? T(1) : T(0);
+  }
+  const int ring = npad - 1;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (int step = 0; step < ring; ++step) {
+      for (int pair = grp; pair < npad / 2; pair += ngrp) {
+        // round-robin tournament: player 0 is fixed, the others rotate (TournamentPair)
+        auto player = [&](int pos) {
+          if (pos == 0) return 0;
+          int r = pos - 1 + step;
+          if (r >= ring) r -= ring;
+          return 1 + r;
+        };
+        int p = player(pair), q = player(npad - 1 - pair);
+        if (p >= n || q >= n) continue;  // the dummy player of an odd tournament
+        if (p > q) {
+          const int t = p;
+          p = q;
+          q = t;
+        }
+        T* wp = W + p * m;
+        T* wq = W + q * m;
+        double a = 0, b = 0, g = 0;
+        for (int i = lane; i < m; i += G) {
+          const double x = static_cast<double>(wp[i]), y = static_cast<double>(wq[i]);
+          a += x * x;
+          b += y * y;
+          g += x * y;
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) {
+          a += __shfl_xor(a, off, 64);
+          b += __shfl_xor(b, off, 64);
+          g += __shfl_xor(g, off, 64);
+        }
+        // The sums are fp64; the rotation itself is formed and applied in the storage precision.
+        const T gt = static_cast<T>(g), dt = static_cast<T>(b - a);
+        const T lim = static_cast<T>(tol) * (sqrt(static_cast<T>(a)) * sqrt(static_cast<T>(b)));
+        if (!(fabs(gt) > lim) || gt == T(0)) continue;  // same decision in the group
+        const T zeta = dt / (T(2) * gt);
+        const T t = (zeta >= T(0) ? T(1) : T(-1)) / (fabs(zeta) + sqrt(T(1) + zeta * zeta));
+        const T c = T(1) / sqrt(T(1) + t * t), sn = c * t;
+        if (lane == 0) rotated = 1;
+        for (int i = lane; i < m; i += G) {
+          const T x = wp[i], y = wq[i];
+          wp[i] = c * x - sn * y;
+          wq[i] = sn * x + c * y;
+        }
+        T* vp = V + p * n;
+        T* vq = V + q * n;
+        for (int i = lane; i < n; i += G) {
+          const T x = vp[i], y = vq[i];
+          vp[i] = c * x - sn * y;
+          vq[i] = sn * x + c * y;
+        }
+      }
+      __syncthreads();
+    }
+    const int any = rotated;
+    __syncthreads();  // everyone has read the flag before the next sweep clears it
+    if (any == 0) break;
+  }
+  for (int i = tid; i < m * n; i += kSmallThreads) Wg[i] = W[i];
+  for (int i = tid; i < n * n; i += kSmallThreads) Vg[i] = V[i];
+  if (tid == 0) *sweeps_out = sweeps;
+}
+
+template <class T> bool SmallJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps,
+                                       double tol, bool warm, int* sweeps) {
+  const size_t bytes = static_cast<size_t>(m * n + n * n) * sizeof(T);
+  if (bytes > kSmallLdsBytes) return false;
+  static const bool big_lds_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&SmallJacobiSvdKernel<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(kSmallLdsBytes)) == hipSuccess;
+  }();
+  if (!big_lds_ok && bytes > 60 * 1024) return false;
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  auto out = rt.Alloc(sizeof(int));
+  const int64_t npad = n + (n & 1);
+  hipLaunchKernelGGL(SmallJacobiSvdKernel<T>, dim3(1), dim3(kSmallThreads), bytes, s, W.as<T>(),
+                     static_cast<int>(m), static_cast<int>(n), V.as<T>(), static_cast<int>(npad), tol,
+                     max_sweeps, warm ? 1 : 0, static_cast<int*>(out->p));
+  EPS_HIP(hipGetLastError());
+  EPS_HIP(hipMemcpyAsync(sweeps, out->p, sizeof(int), hipMemcpyDeviceToHost, s));
+  EPS_HIP(hipStreamSynchronize(s));
+  return true;
+}
+
 // sigma[j] = ||W[:, j]||_2
 template <class T>
 __global__ __launch_bounds__(kBlock) void ColNormKernel(const T* W, int64_t m, int64_t n,
@@ -281,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void GatherColsKernel(T* __restrict__ dst, 
 }
 
 template <class T>
-int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps) {
+int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm) {
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   const DType dt = W.dt;
@@ -301,7 +421,13 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
   DVec Vp = DVec::Zeros(npad * npad, dt), Vt = DVec::Empty(npad * npad, dt);
   EPS_HIP(hipMemcpy2DAsync(Wp.data(), mp * sizeof(T), W.data(), m * sizeof(T), m * sizeof(T), n,
                            hipMemcpyDeviceToDevice, s));
-  AddDiag(Vp, npad, npad, 1.0, nullptr);
+  if (warm) {  // V holds the orthogonal start; identity on the padding columns
+    EPS_HIP(hipMemcpy2DAsync(Vp.data(), npad * sizeof(T), V.data(), n * sizeof(T), n * sizeof(T), n,
+                             hipMemcpyDeviceToDevice, s));
+    if (npad > n) AddDiag(Vp.Slice(n + n * npad, Vp.n - (n + n * npad)), npad - n, npad, 1.0, nullptr);
+  } else {
+    AddDiag(Vp, npad, npad, 1.0, nullptr);
+  }
   DVec G = DVec::Empty(nsplit * h * kJN * kJN, dt), J = DVec::Empty(h * kJN * kJN, dt);
   // round-robin: position layout [top_0 bot_0 top_1 bot_1 ...]; after a step
   //   new_top[0] = top[0], new_top[1] = bot[0], new_top[k] = top[k-1] (k >= 2),
@@ -391,30 +517,47 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
 
 }  // namespace
 
-int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps) {
+int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm) {
   EPS_CHECK(W.n >= m * n && V.n >= n * n && W.dt == V.dt);
   if (m == 0 || n == 0) return 0;
   ProfScope prof("block_jacobi_svd", m, n);
-  return W.dt == F32 ? BlockJacobiImpl<float>(W, m, n, V, max_sweeps)
-                     : BlockJacobiImpl<double>(W, m, n, V, max_sweeps);
+  return W.dt == F32 ? BlockJacobiImpl<float>(W, m, n, V, max_sweeps, warm)
+                     : BlockJacobiImpl<double>(W, m, n, V, max_sweeps, warm);
 }
 
-int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps) {
+int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm) {
   EPS_CHECK(W.n >= m * n && V.n >= n * n && W.dt == V.dt);
   if (m == 0 || n == 0) return 0;
   {
     const char* env = std::getenv("EPSILON_HIP_SVD");  // "scalar" | "block" (read per call)
     const bool force_scalar = env && env[0] == 's', force_block = env && env[0] == 'b';
-    if (!force_scalar && (force_block || n >= 1536)) return BlockJacobiSvd(W, m, n, V, max_sweeps);
+    if (!force_scalar && (force_block || n >= 1536)) return BlockJacobiSvd(W, m, n, V, max_sweeps, warm);
   }
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   ProfScope prof("jacobi_svd", m, n);
   const bool f32 = W.dt == F32;
   const double tol = f32 ? 2e-7 : 1e-15;
+  {
+    const char* env = std::getenv("EPSILON_HIP_SVD");
+    int done = 0;
+    if (!(env && env[0] == 's') && n >= 2 &&
+        (f32 ? SmallJacobiSvd<float>(W, m, n, V, max_sweeps, tol, warm, &done)
+             : SmallJacobiSvd<double>(W, m, n, V, max_sweeps, tol, warm, &done))) {
+      if (std::getenv("EPSILON_HIP_SVD_VERBOSE"))
+        std::fprintf(stderr, "[svd] on-chip %lld x %lld: %d sweeps\n", static_cast<long long>(m),
+                     static_cast<long long>(n), done);
+      return done;
+    }
+  }
   const int64_t total = n * n;
-  if (f32) hipLaunchKernelGGL(EyeKernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, V.as<float>(), n);
-  else hipLaunchKernelGGL(EyeKernel<double>, dim3((total + 255) / 256), dim3(256), 0, s, V.as<double>(), n);
+  if (warm) {
+    // V already holds the orthogonal start
+  } else if (f32) {
+    hipLaunchKernelGGL(EyeKernel<float>, dim3((total + 255) / 256), dim3(256), 0, s, V.as<float>(), n);
+  } else {
+    hipLaunchKernelGGL(EyeKernel<double>, dim3((total + 255) / 256), dim3(256), 0, s, V.as<double>(), n);
+  }
   if (n == 1) return 0;
   const int64_t npad = n + (n & 1);
   auto flag_buf = rt.Alloc(sizeof(int));
@@ -435,6 +578,9 @@ int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps
     EPS_HIP(hipStreamSynchronize(s));
     if (h == 0) break;
   }
+  if (std::getenv("EPSILON_HIP_SVD_VERBOSE"))
+    std::fprintf(stderr, "[svd] step launches %lld x %lld: %d sweeps\n", static_cast<long long>(m),
+                 static_cast<long long>(n), sweeps);
   return sweeps;
 }
 

@@ -4,6 +4,7 @@
 // reference's plugin interface (prox/prox.h:37-77) and cites the file it restates; the numeric
 // work is in kernels_segprox.hip / kernels_svd.hip.
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "prox.h"
@@ -297,6 +298,10 @@ class OrthoInvariantProx : public VectorProx {
     EPS_CHECK_MSG(!symmetric_part_ || m_ == n_, "symmetric matrix function of a non-square argument");
     dtype_ = arg.data_map()->dtype();
     eigen_prox_.reset();
+    V_prev_ = DVec();
+    calls_ = 0;
+    const char* e = std::getenv("EPSILON_HIP_SVD_WARM");
+    warm_start_ = !(e && e[0] == '0');
   }
 
  protected:
@@ -328,8 +333,30 @@ class OrthoInvariantProx : public VectorProx {
     } else {
       W = y.Clone();
     }
-    DVec V = DVec::Empty(n_ * n_, y.dt);
-    k::JacobiSvd(W, m_, n_, V);
+    // Successive applications inside an ADMM run see slowly changing matrices: continue from
+    // the right singular vectors of the previous call (W <- W V_prev; any orthogonal start is
+    // exact) and the Jacobi iteration needs 4-5 sweeps instead of 10-13.  V_prev carries the
+    // rounding of every rotation ever applied to it (a random walk away from orthogonality that
+    // reached 4e-5 after 15 calls in fp32 and moved the stopping sweep of the solve), so it is
+    // first pulled back by one Newton-Schulz step V <- V (3 I - V^T V) / 2, which squares the
+    // defect; every 64th call starts from the identity anyway.
+    DVec V;
+    const bool warm = warm_start_ && V_prev_.n == n_ * n_ && V_prev_.dt == y.dt && (calls_ % 64) != 0;
+    ++calls_;
+    if (warm) {
+      DVec T = DVec::Empty(n_ * n_, y.dt);
+      k::Gemm(true, false, n_, n_, n_, -1.0, V_prev_, n_, V_prev_, n_, 0.0, T, n_);
+      k::AddDiag(T, n_, n_, 3.0, nullptr);
+      V = DVec::Empty(n_ * n_, y.dt);
+      k::Gemm(false, false, n_, n_, n_, 0.5, V_prev_, n_, T, n_, 0.0, V, n_);
+      DVec W0 = DVec::Empty(m_ * n_, y.dt);
+      k::Gemm(false, false, m_, n_, n_, 1.0, W, m_, V, n_, 0.0, W0, m_);
+      W = W0;
+    } else {
+      V = DVec::Empty(n_ * n_, y.dt);
+    }
+    k::JacobiSvd(W, m_, n_, V, 40, warm);
+    V_prev_ = V;
     DVec sigma = DVec::Empty(n_, y.dt);
     k::ColNorms(W, m_, n_, sigma);
     DVec d = sigma;
@@ -402,6 +429,9 @@ class OrthoInvariantProx : public VectorProx {
   AffineOperator eigen_H_, eigen_A_;
   std::unique_ptr<DataMap> eigen_data_;
   std::unique_ptr<ProxOperator> eigen_prox_;
+  DVec V_prev_;  // right singular vectors of the previous application (warm start)
+  int64_t calls_ = 0;
+  bool warm_start_ = true;
 };
 
 #define EPS_ORTHO_OPERATOR(NAME, ...)                         \
