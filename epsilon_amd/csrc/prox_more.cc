@@ -334,28 +334,37 @@ class OrthoInvariantProx : public VectorProx {
       W = y.Clone();
     }
     // Successive applications inside an ADMM run see slowly changing matrices: continue from
-    // the right singular vectors of the previous call (W <- W V_prev; any orthogonal start is
-    // exact) and the Jacobi iteration needs 4-5 sweeps instead of 10-13.  V_prev carries the
-    // rounding of every rotation ever applied to it (a random walk away from orthogonality that
-    // reached 4e-5 after 15 calls in fp32 and moved the stopping sweep of the solve), so it is
-    // first pulled back by one Newton-Schulz step V <- V (3 I - V^T V) / 2, which squares the
-    // defect; every 64th call starts from the identity anyway.
+    // the right singular vectors of the previous call (W <- Y0 V_prev; any orthogonal start is
+    // exact) and the Jacobi iteration needs 4-5 sweeps instead of 10-13; every 64th call starts
+    // from the identity anyway.
+    const DVec Y0 = symmetric_part_ ? W : y;  // the matrix being decomposed (W is overwritten)
     DVec V;
     const bool warm = warm_start_ && V_prev_.n == n_ * n_ && V_prev_.dt == y.dt && (calls_ % 64) != 0;
     ++calls_;
     if (warm) {
-      DVec T = DVec::Empty(n_ * n_, y.dt);
-      k::Gemm(true, false, n_, n_, n_, -1.0, V_prev_, n_, V_prev_, n_, 0.0, T, n_);
-      k::AddDiag(T, n_, n_, 3.0, nullptr);
-      V = DVec::Empty(n_ * n_, y.dt);
-      k::Gemm(false, false, n_, n_, n_, 0.5, V_prev_, n_, T, n_, 0.0, V, n_);
+      V = V_prev_;  // rotated in place; nothing else holds it
       DVec W0 = DVec::Empty(m_ * n_, y.dt);
-      k::Gemm(false, false, m_, n_, n_, 1.0, W, m_, V, n_, 0.0, W0, m_);
+      k::Gemm(false, false, m_, n_, n_, 1.0, Y0, m_, V, n_, 0.0, W0, m_);
       W = W0;
     } else {
+      if (symmetric_part_) W = W.Clone();
       V = DVec::Empty(n_ * n_, y.dt);
     }
     k::JacobiSvd(W, m_, n_, V, 40, warm);
+    {
+      // W and V have been rotated separately thousands of times: in fp32 their rounding is a
+      // random walk that leaves V orthogonal, and W equal to Y0 V, only to ~1e-5 (n = 100) ..
+      // 2e-4 (n = 10^4) - enough to move the stopping sweep of an fp32 solve and to show as a
+      // 0.6 % defect in the optimality certificate at full size.  One Newton-Schulz step
+      // V <- V (3 I - V^T V) / 2 squares the orthogonality defect, and W is re-formed from it.
+      DVec T = DVec::Empty(n_ * n_, y.dt);
+      k::Gemm(true, false, n_, n_, n_, -1.0, V, n_, V, n_, 0.0, T, n_);
+      k::AddDiag(T, n_, n_, 3.0, nullptr);
+      DVec V2 = DVec::Empty(n_ * n_, y.dt);
+      k::Gemm(false, false, n_, n_, n_, 0.5, V, n_, T, n_, 0.0, V2, n_);
+      V = V2;
+      k::Gemm(false, false, m_, n_, n_, 1.0, Y0, m_, V, n_, 0.0, W, m_);
+    }
     V_prev_ = V;
     DVec sigma = DVec::Empty(n_, y.dt);
     k::ColNorms(W, m_, n_, sigma);

@@ -144,3 +144,50 @@ def test_tv1d_prox_full_size(solve_mod):
     assert js <= tol, (js, tol)
     del c, d, jump, cj, dj, v, x
     torch.cuda.empty_cache()
+
+
+def test_nuclear_norm_prox_full_size(solve_mod):
+    """configs[4]'s hot operator at its full size: X = prox_{lam ||.||_*}(Y) for a 10^4 x 10^4
+    matrix (block one-sided Jacobi SVD, kernels_svd.hip).  Certified without a reference SVD by
+    the optimality condition  P = (Y - X) / lam  in the subdifferential of ||.||_* at X:
+    ||P||_2 <= 1 (power iteration) and <X, P> = ||X||_* (nuclear norm of the low-rank X from a
+    randomized range finder whose residual is checked), plus rank(X) = the planted rank."""
+    from epsilon_amd.wire import ProxFunction
+    n, r, lam = 10 ** 4, 10, 4.0
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    # planted singular values ~100: the fp32 decomposition resolves them to ~1e-3, small next to
+    # lam (with values ~1e4 the same relative accuracy is 8 % of lam and the certificate, which
+    # divides Y - X by lam, measures rounding instead of the operator)
+    Y = (torch.randn(n, r, generator=g, device=dev, dtype=torch.float64) @
+         torch.randn(r, n, generator=g, device=dev, dtype=torch.float64)) / 100.0
+    Y += 0.01 * torch.randn(n, n, generator=g, device=dev, dtype=torch.float64)  # ||E||_2 ~ 2 < lam
+    solve_mod.set_option("dtype", "f32")
+    Xv = ir.variable(n, n, "var:X")
+    expr = ir.prox(ProxFunction.NORM_NUCLEAR, Xv)
+    yb = Y.t().contiguous().cpu().numpy().tobytes()  # column-major bytes of Y
+    got = solve_mod.eval_prox(expr.proto.SerializeToString(), lam, expr.data, {"var:X": yb})
+    del yb
+    X = torch.from_numpy(np.frombuffer(got["var:X"]).reshape(n, n).copy()).to(dev).t()  # rows <- columns
+    del got
+    P = (Y - X) / lam
+    # spectral norm of P: power iteration on P^T P
+    v = torch.randn(n, 1, generator=g, device=dev, dtype=torch.float64)
+    for _ in range(60):
+        v = P.t() @ (P @ v)
+        v /= v.norm()
+    sigma_max = float((P @ v).norm())
+    assert sigma_max <= 1.0 + 2e-3, sigma_max
+    # nuclear norm of X (low rank): Q spans its range, X = Q (Q^T X)
+    Om = torch.randn(n, 64, generator=g, device=dev, dtype=torch.float64)
+    Q, _ = torch.linalg.qr(X @ Om)
+    B = Q.t() @ X
+    assert float((X - Q @ B).norm()) <= 1e-6 * float(X.norm())
+    sv = torch.linalg.svdvals(B.cpu())
+    nuc = float(sv.sum())
+    assert int((sv > 1e-6 * sv[0]).sum()) == r
+    inner = float((X * P).sum())
+    assert abs(inner - nuc) <= 2e-3 * nuc, (inner, nuc)
+    del X, Y, P, Q, B
+    torch.cuda.empty_cache()
