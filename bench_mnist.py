@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]: the MNIST multiclass-hinge problem (reference docs/notebooks/mnist.rst:
+X 60000 x 784, k = 10, lam = 1) with the SAMPLES sharded over N GPUs of one node.  Each rank holds
+a row block of X and the matching slices of t, y and the constraint row; Theta is replicated and
+the contractions over samples (X_g^T X_g at Init, X_g^T (...) per sweep: 784 x 10 floats) are the
+all-reduces.  Synthetic data of the MNIST shape (no network).  Not the judged bench line.
+
+  python bench_mnist.py                                    # 1 GPU
+  python -m torch.distributed.run --nproc-per-node 4 --master-addr 127.0.0.1 bench_mnist.py --gpus 4
+  (--comm host: ranks share the visible GPUs through gloo - a rehearsal on a 1-GPU box)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--m", type=int, default=60000)
+    ap.add_argument("--features", type=int, default=784)
+    ap.add_argument("--classes", type=int, default=10)
+    ap.add_argument("--lam", type=float, default=1.0)
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
+    a = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from epsilon_amd import _solve, problems, wire
+    from epsilon_amd import dist as edist
+    assert torch.cuda.is_available() and world == a.gpus
+    if a.comm == "host":
+        local_rank = local_rank % torch.cuda.device_count()
+        os.environ["EPSILON_HIP_DEVICE"] = str(local_rank)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if a.comm == "host":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    _solve.set_option("dtype", "f32")
+    if world > 1:
+        edist.init_comm(rank, world, backend=a.comm)
+        _solve.comm_warmup(1 << 16)
+    else:  # untimed: loads the code objects
+        wp, _ = problems.lasso(256, 1024, seed=1)
+        _solve.solve(wp.SerializeToString(), [], wire.SolverParams(max_iterations=20).SerializeToString(),
+                     wp.expression_data())
+
+    X, Y = problems.multiclass_hinge_data(a.m, a.features, a.classes, seed=0)  # same on every rank
+    lo, hi = edist.column_range(a.m, rank, world, align=1)
+    c_vec = -(X.T.dot(Y)).reshape(1, -1, order="F")                            # the GLOBAL -X^T Y
+    prob, _ = problems.multiclass_hinge(X[lo:hi], Y[lo:hi], a.lam, c_vec=c_vec)
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    if world > 1:
+        _solve.shard_keys(["max_entries:t", "non_negative:y", "constraint:0"])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    s = _solve.Solver(pb, wire.SolverParams(max_iterations=50000).SerializeToString(), data)
+    barrier()
+    t0 = time.time()
+    s.init()
+    barrier()
+    t_init = time.time() - t0
+    s.run(-1)
+    barrier()
+    t_total = time.time() - t0
+    st, x = s.result()
+    S = wire.SolverStatus.FromString(st)
+    Theta = np.frombuffer(x["var:Theta"]).reshape(a.features, a.classes, order="F")
+    s.close()
+    if rank == 0:
+        print(json.dumps({
+            "workload": "multiclass hinge X %dx%d k=%d lam=%g, samples sharded x%d" % (a.m, a.features, a.classes, a.lam, world),
+            "n_gpus": world, "init_s": t_init, "time_to_eps_s": t_total, "sweeps": S.num_iterations + 1,
+            "state": ["NOT_STARTED", "INITIALIZING", "RUNNING", "OPTIMAL", "MAX_ITERATIONS_REACHED", "ERROR"][S.state],
+            "ms_per_sweep": 1e3 * (t_total - t_init) / (S.num_iterations + 1),
+            "objective": problems.multiclass_hinge_objective(X, Y, a.lam, Theta),
+            "residuals": {"r": S.residuals.r_norm, "s": S.residuals.s_norm, "eps_pri": S.residuals.epsilon_primal,
+                          "eps_dual": S.residuals.epsilon_dual},
+            "reference": {"solve_s": 38.75, "iterations": 40, "source": "docs/notebooks/mnist.rst:130-136 (real MNIST, CPU)"},
+            "dtype": "f32", "data": "synthetic",
+        }), flush=True)
+    if dist.is_initialized():
+        _solve.comm_shutdown()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

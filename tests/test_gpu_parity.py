@@ -228,6 +228,24 @@ def test_gemm_mfma_vs_oracle(solve_mod):
     np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_gemm_long_contraction_split_k(solve_mod, dt):
+    """A long contraction into a small result (the X^T R of the multiclass hinge) is split over K
+    into partial products that are added in a fixed order: all transpose combinations, a K that
+    is not a multiple of the chunk, vs numpy."""
+    solve_mod.set_option("dtype", dt)
+    rng = np.random.RandomState(4)
+    for (m, k, n) in [(70, 20011, 33), (200, 9000, 1), (1, 8200, 130)]:
+        for ta in (False, True):
+            for tb in (False, True):
+                A = rng.randn(*((k, m) if ta else (m, k)))
+                B = rng.randn(*((n, k) if tb else (k, n)))
+                _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, tb)
+                ref = (A.T if ta else A).dot(B.T if tb else B)
+                tol = dict(rtol=1e-4, atol=2e-2) if dt == "f32" else dict(rtol=1e-10, atol=1e-9)
+                np.testing.assert_allclose(C, ref, **tol)
+
+
 # ---- proximal operators through eval_prox -----------------------------------------------------------
 
 
