@@ -141,6 +141,14 @@ def main():
     m, n = args.m, args.n
     _solve.set_option("dtype", args.dtype)
     sharded = world > 1 or args.force_sharded
+    # process warm-up (untimed, local to the rank, before any communicator exists): one small
+    # solve of the same structure, so that the code objects are loaded, the library's streams /
+    # events exist and its buffer pool is primed before anything is timed (on a fresh box the
+    # first Init otherwise carries ~20 ms of that)
+    from epsilon_amd import problems
+    wp, _ = problems.lasso(512, 2048, seed=1)
+    _solve.solve(wp.SerializeToString(), [], wire.SolverParams(max_iterations=50).SerializeToString(),
+                 wp.expression_data())
     if sharded:
         from epsilon_amd import dist as edist
         cols = edist.column_range(n, rank, world)
@@ -169,15 +177,7 @@ def main():
         return s
 
     out = {}
-    # ---- process warm-up (untimed): one small solve of the same structure, so that the code
-    # objects are loaded, the library's streams / events exist and its buffer pool is primed
-    # before anything is timed (on a fresh box the first Init otherwise carries ~20 ms of that)
-    if not sharded:
-        from epsilon_amd import problems
-        wp, _ = problems.lasso(512, 2048, seed=1)
-        _solve.solve(wp.SerializeToString(), [], wire.SolverParams(max_iterations=50).SerializeToString(),
-                     wp.expression_data())
-        out["process_warmup"] = "one untimed lasso 512x2048 solve (50 sweeps)"
+    out["process_warmup"] = "one untimed lasso 512x2048 solve (50 sweeps) on every rank"
     # ---- wall-clock-to-eps at the reference defaults (benchmark.py:130-136: max_iterations 50000)
     if not args.no_time_to_eps:
         s = new_solver(wire.SolverParams(max_iterations=50000))
