@@ -355,7 +355,14 @@ class ProxADMMSolver final : public Solver {
     if (f.ls.rhs_arg.n != 0 && !rhs_added) k::Axpby(f.p, 1.0, f.ls.rhs_arg, 1.0);
     const DenseMatrixImpl& D = *f.ls.Dinv_arg;
     Comm* comm = Runtime::Get().comm();
-    if (sharded && comm->size() > 1 && !D.trans() && D.rows() == f.m) {
+    // EPSILON_HIP_SHARDED_APPLY=replicated: every rank applies the whole inverse instead (no
+    // all-gather; m^2 bytes per rank) - the cheaper form when the collective's latency exceeds
+    // the apply, to be decided on the machine
+    static const bool replicated_apply = [] {
+      const char* e = std::getenv("EPSILON_HIP_SHARDED_APPLY");
+      return e && e[0] == 'r';
+    }();
+    if (sharded && comm->size() > 1 && !D.trans() && D.rows() == f.m && !replicated_apply) {
       // The cached inverse is replicated and symmetric: each rank applies only its slab of rows
       // (= columns, read contiguously) and the slices are all-gathered, so the m^2 bytes of the
       // apply are split over the ranks like the data matrix is.

@@ -606,13 +606,16 @@ def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
         np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-3, atol=1e-4, err_msg=k)
 
 
-def test_fused_sweep_sharded(solve_mod, tmp_path):
+@pytest.mark.parametrize("apply_mode", ["slab", "replicated"])
+def test_fused_sweep_sharded(solve_mod, tmp_path, apply_mode):
     """Fused pass on column slabs with the all-reduce between the pass and the cached-inverse
-    apply (3 ranks sharing this GPU, fp32)."""
+    apply (3 ranks sharing this GPU, fp32); the inverse applied by row slabs + all-gather
+    (default) or whole on every rank."""
     from tests import mp_util
     m, n = 40, 101
     x0, x1, status, parts = mp_util.run_ranks(3, "hip", str(tmp_path), m, n, seed=3,
-                                              env_extra={"EPS_TEST_DTYPE": "f32"})
+                                              env_extra={"EPS_TEST_DTYPE": "f32",
+                                                         "EPSILON_HIP_SHARDED_APPLY": apply_mode})
     prob, info = problems.lasso(m, n, seed=3)
     st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams().SerializeToString(),
                       prob.expression_data())
