@@ -279,6 +279,28 @@ def main():
                     "min_hbm_bytes_per_launch": moved,
                     "moved_GBs": moved / (avg_ms * 1e-3) / 1e9,
                     "frac_on_moved_bytes": moved / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # measured HBM ceilings on this device ("fraction of achievable" beside the
+    # fraction of the vendor peak): the resident matrix read once by a plain streaming kernel,
+    # and a device copy of it
+    if roofline is not None and args.dtype == "f32":
+        import ctypes
+        L = _solve.lib()
+        nbytes = At.numel() * 4
+        ms = ctypes.c_double()
+        ceil = {}
+        for name, mode in (("read_nt", 0), ("read", 1), ("copy", 2)):
+            best = 0.0
+            for grid in (512, 1024, 2048, 4096):  # the best launch shape is the ceiling
+                _solve._check(L.eps_bench_stream(ctypes.c_void_p(At.data_ptr()), ctypes.c_size_t(nbytes),
+                                                 ctypes.c_int(mode), ctypes.c_int(grid), ctypes.c_int(10),
+                                                 ctypes.byref(ms)))
+                moved_b = nbytes * (2 if mode == 2 else 1)
+                best = max(best, moved_b / (ms.value * 1e-3) / 1e9)
+            ceil[name + "_GBs"] = best
+        best_read = max(ceil["read_nt_GBs"], ceil["read_GBs"])
+        roofline["achievable"] = dict(ceil, note="StreamReadKernel / StreamCopyKernel over the same %.2f GB, "
+                                      "HIP events, best of four grid sizes, 10 launches each" % (nbytes / 1e9),
+                                      frac_of_achievable_read=roofline["moved_GBs"] / best_read)
     sweep_bytes = (2 * m * n_loc + m * m) * sz
     out.update({
         "metric": "ADMM iters/sec, dense Lasso 1e4x5e4", "value": args.steps / dt,

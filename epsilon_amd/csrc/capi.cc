@@ -483,6 +483,30 @@ int eps_bench_gemv(int trans, int64_t rows, int64_t cols, int iters, double* ms_
   });
 }
 
+int eps_bench_stream(const void* device_ptr, size_t bytes, int mode, int grid, int iters,
+                     double* ms_avg) {
+  return Guard([&] {
+    EPS_CHECK_MSG(bytes >= 16 && mode >= 0 && mode <= 2, "eps_bench_stream: bad arguments");
+    Runtime& rt = Runtime::Get();
+    DVec own;
+    const void* src = device_ptr;
+    if (src == nullptr) {
+      own = Synthetic(static_cast<int64_t>(bytes / 4), F32, 1.0);
+      src = own.data();
+    }
+    EPS_HIP(hipDeviceSynchronize());  // a borrowed pointer may still be written by another stream
+    DVec dst;
+    if (mode == 2) dst = DVec::Empty(static_cast<int64_t>(bytes / 4), F32);
+    if (grid <= 0) grid = 2048;
+    DVec scratch = DVec::Empty(grid, F32);
+    *ms_avg = TimeLaunches(iters, [&] {
+      k::StreamProbe(mode, src, mode == 2 ? dst.data() : nullptr, static_cast<int64_t>(bytes),
+                     scratch.as<float>(), grid);
+    });
+    (void)rt;
+  });
+}
+
 int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int lower_only,
                    int iters, double* ms_avg) {
   return Guard([&] {

@@ -74,6 +74,8 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                  double beta, const DVec& C, int64_t ldc, int64_t sC, int64_t batch,
                  bool lower_only = false, int64_t outer = 1, int64_t sA2 = 0, int64_t sB2 = 0);
 void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc);
+// HBM ceiling probes: mode 0 read (non-temporal), 1 read, 2 copy; scratch holds `grid` floats.
+void StreamProbe(int mode, const void* src, void* dst, int64_t bytes, float* scratch, int grid);
 
 // dst (rows x cols, ld = rows) = alpha * op(src)
 void MatCopy(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& src,

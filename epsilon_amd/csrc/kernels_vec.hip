@@ -404,5 +404,66 @@ void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVe
                                           nA, B.as<T>(), mB, nB));
 }
 
+
+// ---- HBM ceiling probes (measurement only: bench.py reports the sweep against them) ------------
+namespace {
+typedef float f32x4_probe __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ __launch_bounds__(256) void StreamReadKernel(const f32x4_probe* __restrict__ p, int64_t n4,
+                                                        float* __restrict__ out) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  float acc = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four 16-byte loads in flight per thread
+    f32x4_probe v0, v1, v2, v3;
+    if (NT) {
+      v0 = __builtin_nontemporal_load(p + i);
+      v1 = __builtin_nontemporal_load(p + i + stride);
+      v2 = __builtin_nontemporal_load(p + i + 2 * stride);
+      v3 = __builtin_nontemporal_load(p + i + 3 * stride);
+    } else {
+      v0 = p[i];
+      v1 = p[i + stride];
+      v2 = p[i + 2 * stride];
+      v3 = p[i + 3 * stride];
+    }
+    acc += (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w) + (v2.x + v2.y + v2.z + v2.w) +
+           (v3.x + v3.y + v3.z + v3.w);
+  }
+  for (; i < n4; i += stride) {
+    const f32x4_probe v = p[i];
+    acc += v.x + v.y + v.z + v.w;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (static_cast<int>(threadIdx.x) < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void StreamCopyKernel(const f32x4_probe* __restrict__ src,
+                                                        f32x4_probe* __restrict__ dst, int64_t n4) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n4; i += stride)
+    dst[i] = src[i];
+}
+}  // namespace
+
+void StreamProbe(int mode, const void* src, void* dst, int64_t bytes, float* scratch, int grid) {
+  hipStream_t s = Runtime::Get().stream();
+  const int64_t n4 = bytes / 16;
+  const auto* p = static_cast<const f32x4_probe*>(src);
+  if (mode == 0)
+    hipLaunchKernelGGL(StreamReadKernel<true>, dim3(grid), dim3(256), 0, s, p, n4, scratch);
+  else if (mode == 1)
+    hipLaunchKernelGGL(StreamReadKernel<false>, dim3(grid), dim3(256), 0, s, p, n4, scratch);
+  else
+    hipLaunchKernelGGL(StreamCopyKernel, dim3(grid), dim3(256), 0, s, p, static_cast<f32x4_probe*>(dst), n4);
+}
+
 }  // namespace k
 }  // namespace eps

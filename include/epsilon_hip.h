@@ -182,6 +182,13 @@ int eps_linear_map_inverse(const void* linear_map, size_t len, const eps_blob* d
 /* Micro-benchmark of the dense mat-vec kernels on device-resident synthetic data: average
  * milliseconds per launch over `iters` launches (HIP events on the solver stream). */
 int eps_bench_gemv(int trans, int64_t rows, int64_t cols, int iters, double* ms_avg);
+/* HBM ceiling probe on `bytes` of device memory (device_ptr, 16-byte aligned, or NULL for a
+ * synthetic buffer): mode 0 = read-only with non-temporal loads, 1 = read-only, 2 = copy to a
+ * scratch buffer (bytes read + bytes written); grid = workgroups of 256 threads (0: 2048).
+ * Measurement only: bench.py reports the sweep as
+ * a fraction of these beside the 8 TB/s vendor peak. */
+int eps_bench_stream(const void* device_ptr, size_t bytes, int mode, int grid, int iters,
+                     double* ms_avg);
 /* Same for C = op(A) op(B) (M x N x K); lower_only = SYRK-style. */
 int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int lower_only,
                    int iters, double* ms_avg);
