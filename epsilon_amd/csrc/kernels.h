@@ -130,14 +130,16 @@ void ZoneEpigraphSums(int64_t n, const double* key, const double* w2, double lam
 // input equals W V^T; V (n x n) is overwritten.  Returns the number of sweeps used.
 // warm: V holds an orthogonal matrix on entry and W has already been multiplied by it (the
 // decomposition continues from there: Y = W V^T holds throughout).
+// row_sharded: W holds this rank's block of rows (V replicated); the column inner products are
+// all-reduced over the communicator (block form only).
 int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40,
-              bool warm = false);
+              bool warm = false, bool row_sharded = false);
 // The same decomposition by the block algorithm (pairs of 32-column panels: batched Gram on the
 // MFMA kernel, 64 x 64 eigenproblems on chip, batched GEMM updates); JacobiSvd switches to it
 // from 1536 columns up (measured crossover on MI355X; EPSILON_HIP_SVD=block|scalar forces one).
 int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40,
-                   bool warm = false);
-void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma);
+                   bool warm = false, bool row_sharded = false);
+void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma, bool row_sharded = false);
 // W[:, j] *= xt[j] / sigma[j]   (0 where sigma[j] == 0, as ortho_invariant.cc:44-49)
 void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt);
 

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <vector>
 
+#include "comm.h"
 #include "kernels.h"
 
 namespace eps {
@@ -293,7 +294,7 @@ template <class T> bool SmallJacobiSvd(const DVec& W, int64_t m, int64_t n, cons
 // sigma[j] = ||W[:, j]||_2
 template <class T>
 __global__ __launch_bounds__(kBlock) void ColNormKernel(const T* W, int64_t m, int64_t n,
-                                                        T* sigma) {
+                                                        T* sigma, int squared = 0) {
   __shared__ double red[kBlock / 64];
   const int64_t j = blockIdx.x;
   double a = 0;
@@ -307,8 +308,13 @@ __global__ __launch_bounds__(kBlock) void ColNormKernel(const T* W, int64_t m, i
   if (threadIdx.x == 0) {
     double t = 0;
     for (int w = 0; w < kBlock / 64; ++w) t += red[w];
-    sigma[j] = static_cast<T>(sqrt(t));
+    sigma[j] = static_cast<T>(squared ? t : sqrt(t));
   }
+}
+
+template <class T> __global__ void SqrtInPlaceKernel(T* x, int64_t n) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x;
+  if (i < n) x[i] = sqrt(x[i]);
 }
 
 // W[:, j] *= (sigma[j] != 0 ? xt[j] / sigma[j] : 0)
@@ -462,7 +468,8 @@ __global__ __launch_bounds__(kBlock) void GatherColsKernel(T* __restrict__ dst, 
 }
 
 template <class T>
-int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm) {
+int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm,
+                    bool row_sharded) {
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   const DType dt = W.dt;
@@ -473,15 +480,22 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
   const double done_tol = dt == F32 ? 3e-6 : 1e-13;  // max |cos| between columns at convergence
   // split-K for the Gram products so that more than h workgroups run; rows are padded with
   // zeros to nsplit equal chunks of a multiple of 32 rows (16-byte aligned slices)
+  // Row-sharded (each rank holds a block of rows of W, V replicated): the panel Grams are sums
+  // over ranks - one all-reduce per step - after which every rank solves the same small
+  // eigenproblems and applies the same rotations to its rows and to its copy of V.  The split
+  // count must agree across ranks, so it is derived from the largest row block.
+  Comm* comm = row_sharded ? rt.comm() : nullptr;
+  const int64_t m_ref = comm ? static_cast<int64_t>(comm->AllReduceMaxHost(static_cast<double>(m)) + 0.5) : m;
   int64_t nsplit = 1;
-  while (nsplit < 8 && h * nsplit < 512 && m / (nsplit * 2) >= 256) nsplit *= 2;
-  const int64_t kchunk = ((m + nsplit - 1) / nsplit + 31) / 32 * 32;
+  while (nsplit < 8 && h * nsplit < 512 && m_ref / (nsplit * 2) >= 256) nsplit *= 2;
+  const int64_t kchunk = ((m_ref + nsplit - 1) / nsplit + 31) / 32 * 32;
   const int64_t mp = nsplit * kchunk;
   // padded working copies
   DVec Wp = DVec::Zeros(mp * npad, dt), Wt = DVec::Empty(mp * npad, dt);
   DVec Vp = DVec::Zeros(npad * npad, dt), Vt = DVec::Empty(npad * npad, dt);
-  EPS_HIP(hipMemcpy2DAsync(Wp.data(), mp * sizeof(T), W.data(), m * sizeof(T), m * sizeof(T), n,
-                           hipMemcpyDeviceToDevice, s));
+  if (m > 0)
+    EPS_HIP(hipMemcpy2DAsync(Wp.data(), mp * sizeof(T), W.data(), m * sizeof(T), m * sizeof(T), n,
+                             hipMemcpyDeviceToDevice, s));
   if (warm) {  // V holds the orthogonal start; identity on the padding columns
     EPS_HIP(hipMemcpy2DAsync(Vp.data(), npad * sizeof(T), V.data(), n * sizeof(T), n * sizeof(T), n,
                              hipMemcpyDeviceToDevice, s));
@@ -524,6 +538,7 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
       // [sp * kchunk, (sp + 1) * kchunk) of the panels (the last chunk is padded with zero rows)
       GemmBatched(true, false, kJN, kJN, kchunk, 1.0, Wp, mp, kJN * mp, Wp, mp, kJN * mp, 0.0, G,
                   kJN, kJN * kJN, h, false, nsplit, kchunk, kchunk);
+      if (comm) comm->AllReduceSum(G);
       hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
                          G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
                          done_tol, offmax);
@@ -578,21 +593,26 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
 
 }  // namespace
 
-int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm) {
+int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm,
+                   bool row_sharded) {
   EPS_CHECK(W.n >= m * n && V.n >= n * n && W.dt == V.dt);
-  if (m == 0 || n == 0) return 0;
+  if (n == 0 || (m == 0 && !row_sharded)) return 0;  // a rank without rows still joins the collectives
   ProfScope prof("block_jacobi_svd", m, n);
-  return W.dt == F32 ? BlockJacobiImpl<float>(W, m, n, V, max_sweeps, warm)
-                     : BlockJacobiImpl<double>(W, m, n, V, max_sweeps, warm);
+  return W.dt == F32 ? BlockJacobiImpl<float>(W, m, n, V, max_sweeps, warm, row_sharded)
+                     : BlockJacobiImpl<double>(W, m, n, V, max_sweeps, warm, row_sharded);
 }
 
-int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm) {
+int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm,
+              bool row_sharded) {
   EPS_CHECK(W.n >= m * n && V.n >= n * n && W.dt == V.dt);
-  if (m == 0 || n == 0) return 0;
+  if (n == 0) return 0;
+  if (row_sharded) return BlockJacobiSvd(W, m, n, V, max_sweeps, warm, true);  // the sharded form
+  if (m == 0) return 0;
   {
     const char* env = std::getenv("EPSILON_HIP_SVD");  // "scalar" | "block" (read per call)
     const bool force_scalar = env && env[0] == 's', force_block = env && env[0] == 'b';
-    if (!force_scalar && (force_block || n >= 1536)) return BlockJacobiSvd(W, m, n, V, max_sweeps, warm);
+    if (!force_scalar && (force_block || n >= 1536))
+      return BlockJacobiSvd(W, m, n, V, max_sweeps, warm, false);
   }
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
@@ -645,14 +665,21 @@ int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps
   return sweeps;
 }
 
-void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma) {
+void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma, bool row_sharded) {
   EPS_CHECK(W.n >= m * n && sigma.n == n && W.dt == sigma.dt);
   if (n == 0) return;
   hipStream_t s = Runtime::Get().stream();
+  const int sq = row_sharded ? 1 : 0;  // rows on other ranks: sum the squares first
   if (W.dt == F32)
-    hipLaunchKernelGGL(ColNormKernel<float>, dim3(n), dim3(kBlock), 0, s, W.as<float>(), m, n, sigma.as<float>());
+    hipLaunchKernelGGL(ColNormKernel<float>, dim3(n), dim3(kBlock), 0, s, W.as<float>(), m, n, sigma.as<float>(), sq);
   else
-    hipLaunchKernelGGL(ColNormKernel<double>, dim3(n), dim3(kBlock), 0, s, W.as<double>(), m, n, sigma.as<double>());
+    hipLaunchKernelGGL(ColNormKernel<double>, dim3(n), dim3(kBlock), 0, s, W.as<double>(), m, n, sigma.as<double>(), sq);
+  if (row_sharded) {
+    Runtime::Get().comm()->AllReduceSum(sigma);
+    const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+    if (W.dt == F32) hipLaunchKernelGGL(SqrtInPlaceKernel<float>, dim3(grid), dim3(256), 0, s, sigma.as<float>(), n);
+    else hipLaunchKernelGGL(SqrtInPlaceKernel<double>, dim3(grid), dim3(256), 0, s, sigma.as<double>(), n);
+  }
 }
 
 void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt) {

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "comm.h"
 #include "kernels.h"
 #include "prox.h"
 
@@ -309,6 +310,13 @@ class OrthoInvariantProx : public VectorProx {
     if (!eigen_prox_) InitEigenProx(epigraph_ ? 1.0 : input.lambda());
     const DVec& y = input.value_vec(0);
     EPS_CHECK(y.n == m_ * n_);
+    // Sharded solve with the matrix argument split by rows over the ranks (m_ = this rank's
+    // rows): the decomposition runs in its row-sharded form - panel Grams and column norms are
+    // all-reduced, the n x n factor V and the singular values are replicated.
+    const ShardSpec& shard = ShardSpec::Get();
+    const bool row_sharded = shard.active() && shard.IsSharded(affine::arg_key(0));
+    EPS_CHECK_MSG(!(row_sharded && symmetric_part_),
+                  "symmetric matrix functions are not available on a row-sharded argument");
     DVec W, R;
     double shift = 0;
     if (symmetric_part_) {
@@ -350,7 +358,7 @@ class OrthoInvariantProx : public VectorProx {
       if (symmetric_part_) W = W.Clone();
       V = DVec::Empty(n_ * n_, y.dt);
     }
-    k::JacobiSvd(W, m_, n_, V, 40, warm);
+    k::JacobiSvd(W, m_, n_, V, 40, warm, row_sharded);
     {
       // W and V have been rotated separately thousands of times: in fp32 their rounding is a
       // random walk that leaves V orthogonal, and W equal to Y0 V, only to ~1e-5 (n = 100) ..
@@ -367,7 +375,7 @@ class OrthoInvariantProx : public VectorProx {
     }
     V_prev_ = V;
     DVec sigma = DVec::Empty(n_, y.dt);
-    k::ColNorms(W, m_, n_, sigma);
+    k::ColNorms(W, m_, n_, sigma, row_sharded);
     DVec d = sigma;
     if (symmetric_part_) {
       d = DVec::Full(n_, -shift, y.dt);
@@ -375,6 +383,8 @@ class OrthoInvariantProx : public VectorProx {
     }
     BlockVector in;
     DVec xt, t;
+    // the nested prox works on the replicated singular values: nothing in it is sharded
+    LocalShardScope replicated_scope{std::set<std::string>()};
     if (epigraph_) {  // ApplyEigenEpigraph (:107-116)
       in.Set(affine::arg_key(0), d);
       in.Set(affine::arg_key(1), input.value_vec(1));

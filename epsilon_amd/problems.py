@@ -160,15 +160,22 @@ def robust_pca_data(n, r=10, density=0.1, seed=0):
     return np.asarray(L0 + S0.toarray())
 
 
-def robust_pca(n, r=10, density=0.1, seed=0, lam=0.1):
-    """norm_nuclear(L) + lam*norm_1(S)  s.t.  L + S - M = 0  (SURVEY 3.4b)."""
-    M = robust_pca_data(n, r, density, seed)
-    L = ir.variable(n, n, "var:L")
-    S = ir.variable(n, n, "var:S")
+def robust_pca_ir(M, lam):
+    """norm_nuclear(L) + lam*norm_1(S)  s.t.  L + S - M = 0   for an m x n block M:
+    the whole matrix, or one rank's block of rows in a row-sharded solve (keys var:L, var:S and
+    constraint:0 sharded; the nuclear-norm prox then runs its row-sharded SVD)."""
+    m, n = M.shape
+    L = ir.variable(m, n, "var:L")
+    S = ir.variable(m, n, "var:S")
     f0 = ir.prox(ProxFunction.NORM_NUCLEAR, L, alpha=1.0)
     f1 = ir.prox(ProxFunction.NORM_1, S, alpha=lam)
-    c = ir.zero(ir.add(L, S, ir.linear_map(ir.scalar(-1, n * n), ir.constant(M.reshape(-1, 1, order="F")))))
-    return ir.Problem([f0, f1], [c]), dict(M=M, lam=lam)
+    c = ir.zero(ir.add(L, S, ir.linear_map(ir.scalar(-1, m * n), ir.constant(M.reshape(-1, 1, order="F")))))
+    return ir.Problem([f0, f1], [c])
+
+
+def robust_pca(n, r=10, density=0.1, seed=0, lam=0.1):
+    M = robust_pca_data(n, r, density, seed)
+    return robust_pca_ir(M, lam), dict(M=M, lam=lam)
 
 
 def robust_pca_objective(lam, Lm, Sm):

@@ -6,6 +6,11 @@ mode "oracle": numpy emulation of the column-sharded (E1) lasso sweep with gloo 
 mode "oracle_consensus": numpy emulation of the consensus-form (E2) lasso, rows of A split over
                the ranks, z-averaging and residual sums over gloo (runs on CPU).
 mode "hip_consensus": the HIP solver on the per-rank consensus problem (host-callback comm).
+mode "oracle_rpca": numpy emulation of the row-sharded robust PCA sweep: singular value
+               thresholding through the all-reduced Gram matrix Y^T Y (the reference's own route,
+               ortho_invariant.cc:36-50), norms through all-reduced partial sums (runs on CPU).
+mode "hip_rpca": robust PCA with the matrix split by ROWS over the ranks (row-sharded SVD in the
+               nuclear-norm prox; m is the matrix size, n is ignored).
 mode "hip"   : the real HIP solver, one rank per process, collectives through the host-callback
                backend over gloo (ranks may share one GPU).
 Each rank writes its slice of the result to <out>/rank<r>.npz.
@@ -97,6 +102,77 @@ def main():
                 it += 1
             np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x0=xg, x1=z, lo=lo, hi=hi,
                      status=np.array(status))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if mode == "oracle_rpca":
+        nn = m
+        M = problems.robust_pca_data(nn, r=3, density=0.1, seed=seed)
+        lo, hi = edist.column_range(nn, rank, world, align=1)
+        Mg = M[lo:hi]
+        lam_s = 0.1
+        b = -Mg
+        shape = Mg.shape
+        u = np.zeros(shape); y0 = np.zeros(shape); y1 = np.zeros(shape)
+        Lg = np.zeros(shape); Sg = np.zeros(shape)
+
+        def svt_rows(Y):  # prox of ||.||_* on the row-sharded matrix: eig of the summed Gram
+            G = allreduce(Y.T.dot(Y) + (1e-15 / world) * np.eye(nn))
+            w, V = np.linalg.eigh(G)
+            sig = np.sqrt(np.maximum(w, 0))
+            shr = np.maximum(sig - 1.0, 0)
+            scale = np.where(sig > 0, shr / np.where(sig > 0, sig, 1), 0)
+            return (Y.dot(V) * scale).dot(V.T)
+
+        def nsq(*arrs):
+            return allreduce(np.array([np.sum(a ** 2) for a in arrs]))
+
+        it, status = 0, None
+        while it < max_iter:
+            y1_prev = y1.copy()
+            u = u - b - y0 - y1
+            u = u + y0
+            Lg = svt_rows(u)
+            y0 = Lg.copy()
+            u = u - y0
+            u = u + y1
+            Sg = np.sign(u) * np.maximum(np.abs(u) - lam_s, 0)
+            y1 = Sg.copy()
+            u = u - y1
+            if it % 10 == 0:
+                q = nsq(y0 + y1 + b, y1 - y1_prev, b, y0, y1, u)
+                r, sn = np.sqrt(q[0]), np.sqrt(q[1])
+                ep = 1e-4 * np.sqrt(nn * nn) + 1e-2 * np.sqrt(max(q[2], q[3], q[4]))
+                ed = 1e-4 * np.sqrt(2 * nn * nn) + 1e-2 * np.sqrt(2 * q[5])
+                status = (it, r, sn, ep, ed)
+                if r <= ep and sn <= ed:
+                    break
+            it += 1
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x0=Lg, x1=Sg, lo=lo, hi=hi,
+                 status=np.array(status))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if mode == "hip_rpca":
+        from epsilon_amd import _solve
+        nn = m
+        M = problems.robust_pca_data(nn, r=3, density=0.1, seed=seed)
+        lo, hi = edist.column_range(nn, rank, world, align=1)
+        _solve.set_option("dtype", os.environ.get("EPS_TEST_DTYPE", "f64"))
+        edist.init_comm(rank, world, backend="host")
+        prob = problems.robust_pca_ir(np.ascontiguousarray(M[lo:hi]), 0.1)
+        _solve.shard_keys(["var:L", "var:S", "constraint:0"])
+        params = wire.SolverParams(max_iterations=max_iter)
+        st, x = _solve.solve(prob.SerializeToString(), [], params.SerializeToString(),
+                             prob.expression_data())
+        S = wire.SolverStatus.FromString(st)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+                 x0=np.frombuffer(x["var:L"]).reshape(hi - lo, nn, order="F"),
+                 x1=np.frombuffer(x["var:S"]).reshape(hi - lo, nn, order="F"), lo=lo, hi=hi,
+                 status=np.array([S.num_iterations, S.residuals.r_norm, S.residuals.s_norm,
+                                  S.residuals.epsilon_primal, S.residuals.epsilon_dual]),
+                 state=S.state)
+        _solve.comm_shutdown()
         dist.barrier()
         dist.destroy_process_group()
         return

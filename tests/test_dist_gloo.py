@@ -69,3 +69,25 @@ def test_consensus_sweep_equals_single_process(tmp_path, world):
     for g, p in enumerate(parts):
         np.testing.assert_allclose(p["x0"], np.frombuffer(x["var:x_%d" % g]), rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(p["x1"], np.frombuffer(x[problems.CONSENSUS_Z]), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_sharded_robust_pca_equals_single_process(tmp_path, world):
+    """BASELINE.json configs[4] sharded by rows: the singular value thresholding runs through the
+    all-reduced Gram matrix, the residual norms through all-reduced partial sums; the ranks must
+    reproduce the oracle's single-process solve sweep for sweep."""
+    nn = 26
+    x0, x1, status, parts = mp_util.run_ranks(world, "oracle_rpca", str(tmp_path), nn, 8, seed=2,
+                                              max_iter=400)
+    M = problems.robust_pca_data(nn, r=3, density=0.1, seed=2)
+    prob = problems.robust_pca_ir(M, 0.1)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams(max_iterations=400).SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    for s in status:
+        assert int(s[0]) == S.num_iterations
+        np.testing.assert_allclose(s[1:], [S.residuals.r_norm, S.residuals.s_norm,
+                                           S.residuals.epsilon_primal, S.residuals.epsilon_dual],
+                                   rtol=1e-6)
+    np.testing.assert_allclose(x0, np.frombuffer(x["var:L"]).reshape(nn, nn, order="F"), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(x1, np.frombuffer(x["var:S"]).reshape(nn, nn, order="F"), rtol=1e-6, atol=1e-8)

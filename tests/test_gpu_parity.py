@@ -546,6 +546,33 @@ def test_consensus_form_solve(solve_mod, tmp_path, world, dt):
         np.testing.assert_allclose(p["x1"], np.frombuffer(x[problems.CONSENSUS_Z]), **tol)
 
 
+@pytest.mark.parametrize("world,dt,nn", [(2, "f64", 24), (3, "f64", 41), (3, "f32", 70)])
+def test_robust_pca_row_sharded(solve_mod, tmp_path, world, dt, nn):
+    """configs[4] in its sharded form: the matrix split by rows over the ranks, the nuclear-norm
+    prox running the row-sharded block Jacobi SVD (panel Grams and column norms all-reduced, V
+    and the singular values replicated).  `world` processes sharing this GPU against the oracle's
+    single-process solve: same stopping sweep, residuals and iterates."""
+    from tests import mp_util
+    x0, x1, status, parts = mp_util.run_ranks(world, "hip_rpca", str(tmp_path), nn, 8, seed=2,
+                                              max_iter=400, env_extra={"EPS_TEST_DTYPE": dt})
+    M = problems.robust_pca_data(nn, r=3, density=0.1, seed=2)
+    prob = problems.robust_pca_ir(M, 0.1)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams(max_iterations=400).SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    Lref = np.frombuffer(x["var:L"]).reshape(nn, nn, order="F")
+    Sref = np.frombuffer(x["var:S"]).reshape(nn, nn, order="F")
+    tol = dict(rtol=1e-6, atol=1e-7) if dt == "f64" else dict(rtol=5e-3, atol=5e-3)
+    for s, p in zip(status, parts):
+        assert int(p["state"]) == S.state
+        assert int(s[0]) == S.num_iterations
+        np.testing.assert_allclose(s[1:], [S.residuals.r_norm, S.residuals.s_norm,
+                                           S.residuals.epsilon_primal, S.residuals.epsilon_dual],
+                                   rtol=1e-5 if dt == "f64" else 2e-2)
+    np.testing.assert_allclose(x0, Lref, **tol)   # run_ranks stacks the row blocks
+    np.testing.assert_allclose(x1, Sref, **tol)
+
+
 def test_rccl_backend_single_rank(solve_mod):
     """RCCL backend end to end (dlopen, unique id, ncclCommInitRank, ncclAllReduce on the solver
     stream) on a 1-rank communicator with the sharded code path forced on."""
