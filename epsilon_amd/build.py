@@ -23,6 +23,7 @@ DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_prox.hip", ["-ffp-contract=off"]),
                   ("kernels_fused.hip", ["-ffp-contract=off"]),
                   ("kernels_gemv.hip", []),
+                  ("kernels_gemv_multi.hip", []),
                   ("kernels_gemm.hip", []),
                   ("kernels_factor.hip", []),
                   ("kernels_sparse.hip", []),

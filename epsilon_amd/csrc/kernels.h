@@ -74,6 +74,10 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                  double beta, const DVec& C, int64_t ldc, int64_t sC, int64_t batch,
                  bool lower_only = false, int64_t outer = 1, int64_t sA2 = 0, int64_t sB2 = 0);
 void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc);
+// C (M x N, ldc == M, N <= 16) = alpha op(A) B + beta C as a mat-vec with N right-hand sides
+// (kernels_gemv_multi.hip); false if the shape / alignment is not covered (nothing is done).
+bool MultiGemv(bool transA, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,
+               const DVec& B, int64_t ldb, double beta, const DVec& C, int64_t ldc);
 // HBM ceiling probes: mode 0 read (non-temporal), 1 read, 2 copy; scratch holds `grid` floats.
 void StreamProbe(int mode, const void* src, void* dst, int64_t bytes, float* scratch, int grid);
 

@@ -452,6 +452,10 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
   // K = 60000) has a handful of output tiles, each looping over all of K on one workgroup - 7
   // workgroups on 256 CUs, 7.3 ms.  Split K over batches into partial results and add them in
   // a fixed order (deterministic): 29 x 7 workgroups, ~0.1 ms.
+  // a few right-hand sides: a mat-vec that reads the matrix once, not a matrix product
+  if (!transB && !lower_only && N <= 16 && M * K >= (int64_t(1) << 18) &&
+      MultiGemv(transA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc))
+    return;
   const int64_t tiles = ((M + MT - 1) / MT) * ((N + MT - 1) / MT);
   if (!lower_only && tiles <= 64 && K >= 8192 && M > 0 && N > 0) {
     int64_t nsplit = std::min<int64_t>(K / 2048, 512 / tiles);

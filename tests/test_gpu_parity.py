@@ -246,6 +246,25 @@ def test_gemm_long_contraction_split_k(solve_mod, dt):
                 np.testing.assert_allclose(C, ref, **tol)
 
 
+def test_gemm_few_right_hand_sides(solve_mod):
+    """Dense times skinny (<= 16 columns) runs as a mat-vec with several right-hand sides
+    (kernels_gemv_multi.hip: the Kronecker applies of the multiclass problems), both
+    orientations of the matrix, ragged row / column counts, every width class, vs numpy."""
+    solve_mod.set_option("dtype", "f32")
+    rng = np.random.RandomState(6)
+    for (m, k, n) in [(5000, 300, 10), (4100, 257, 3), (1028, 1000, 13), (2052, 130, 16), (60000, 20, 1)]:
+        for ta in (False, True):
+            A = rng.randn(*((k, m) if ta else (m, k)))
+            B = rng.randn(k, n)
+            _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, False)
+            ref = (A.T if ta else A).dot(B)
+            np.testing.assert_allclose(C, ref, rtol=1e-4, atol=5e-3)
+    # long contraction, few outputs (X^T R of the hinge problem)
+    A, B = rng.randn(30000, 36), rng.randn(30000, 10)
+    _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), True, False)
+    np.testing.assert_allclose(C, A.T.dot(B), rtol=1e-4, atol=2e-2)
+
+
 # ---- proximal operators through eval_prox -----------------------------------------------------------
 
 
