@@ -393,8 +393,15 @@ __global__ __launch_bounds__(kBlock) void PairEigKernel(const T* __restrict__ G,
   const int pair = t / kTpp, sub = t % kTpp;
   for (int sw = 0; sw < inner_sweeps; ++sw) {
     for (int step = 0; step < kJN - 1; ++step) {
-      int64_t p, q;
-      TournamentPair(kJN, step, pair, &p, &q);
+      // round-robin tournament, 32-bit and modulo-free (the 64-bit remainders of TournamentPair
+      // were a sizeable part of a step that is otherwise ~40 instructions)
+      auto player = [&](int pos) {
+        if (pos == 0) return 0;
+        int r = pos - 1 + step;
+        if (r >= kJN - 1) r -= kJN - 1;
+        return 1 + r;
+      };
+      const int p = player(pair), q = player(kJN - 1 - pair);
       T* ap = A + p * kJLd;
       T* aq = A + q * kJLd;
       // rotations in the storage precision (these are 64 x 64 problems whose result only has to
