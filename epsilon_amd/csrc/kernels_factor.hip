@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -61,7 +62,7 @@ template <class T> __device__ inline void Pin(T& v) { asm volatile("" : "+v"(v))
 // ONE WAVE, register resident: the pivot column is broadcast lane by lane with v_readlane, so the
 // 64 elimination steps need no LDS and no barriers (an LDS version spent ~190 us per block in
 // ~400 barriers).  Returns true on a non-positive pivot.
-template <class T> __device__ inline bool CholRows(T (&r)[NB], int lane) {
+template <class T> __device__ __forceinline__ bool CholRows(T (&r)[NB], int lane) {
   bool bad = false;
   // right-looking Cholesky: after step j, r[j] holds L[lane][j]
   StaticFor<0, NB>::Run([&](auto jj) {
@@ -225,6 +226,124 @@ __global__ __launch_bounds__(256) void PotrfPanelStepKernel(T* W, int64_t ld, in
   if (q == 0) {
     // forward substitution in 8 x 8 blocks, x written back over T: the outer loops stay rolled
     // (fully unrolled, the compiler hoists all 2016 broadcast reads and spills them)
+#pragma unroll 1
+    for (int jb = 0; jb < NB; jb += 8) {
+      T tv[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) tv[jj] = Tt[jb + jj][r];
+#pragma unroll 1
+      for (int k8 = 0; k8 < jb; k8 += 8) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          const T xk = Tt[k8 + kk][r];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) tv[jj] -= xk * buf[(jb + jj) * NB + k8 + kk];
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+        for (int kk = 0; kk < jj; ++kk) tv[jj] -= tv[kk] * buf[(jb + jj) * NB + jb + kk];
+        tv[jj] /= buf[(jb + jj) * NB + jb + jj];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) Tt[jb + jj][r] = tv[jj];
+    }
+  }
+  __syncthreads();
+  if (live) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = q * 16 + c;
+      if (col < kb) W[row + (k0 + col) * ld] = Tt[col][r];
+    }
+  }
+}
+
+// fp32: the two launches of a step fused.  Every workgroup re-derives the factor of the diagonal
+// block itself (the same instructions on the same data: identical bits) next to its own rows'
+// update - the panel columns it stages serve both - so the 157 steps of a 10^4 matrix are one
+// launch each and the single-workgroup diagonal kernel leaves the critical path.  Workgroup 0
+// writes the factor of the diagonal block back.  (fp64 keeps the two kernels: the third 64 x 64
+// tile does not fit the 64 KB of static LDS.)
+__global__ __launch_bounds__(256) void PotrfFusedStepKernel(float* W, int64_t ld, int64_t n, int64_t K0,
+                                                            int64_t k0, int kb, int* flag) {
+  using T = float;
+  __shared__ T Tt[NB][NB];        // [column][row], this workgroup's rows
+  __shared__ T Dd[NB][NB];        // [column][row], the diagonal block
+  __shared__ T buf[2 * KC * NB];  // stage: Lr[k][row] | Pc[k][col]; afterwards L11 as [j][k]
+  T* Lr = buf;
+  T* Pc = buf + KC * NB;
+  const int t = threadIdx.x, r = t & 63, q = t >> 6;
+  const int64_t row0 = k0 + kb + static_cast<int64_t>(blockIdx.x) * NB;
+  const int64_t row = row0 + r;
+  const bool live = row < n;
+  T acc[16], dac[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = q * 16 + c;
+    acc[c] = (live && col < kb) ? W[row + (k0 + col) * ld] : T(0);
+    T v = (r == col) ? T(1) : T(0);
+    if (r < kb && col < kb && r >= col) v = W[(k0 + r) + (k0 + col) * ld];
+    dac[c] = v;
+  }
+  constexpr int PF = KC * NB / 256;
+  T pfl[PF], pfp[PF];
+  auto fetch = [&](int64_t kk) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = t + i * 256, rr = idx & 63, k = idx >> 6;
+      pfl[i] = (row0 + rr < n) ? W[(row0 + rr) + (kk + k) * ld] : T(0);
+      pfp[i] = rr < kb ? W[(k0 + rr) + (kk + k) * ld] : T(0);
+    }
+  };
+  if (K0 < k0) fetch(K0);
+  for (int64_t kk = K0; kk < k0; kk += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int idx = t + i * 256;
+      Lr[idx] = pfl[i];
+      Pc[idx] = pfp[i];
+    }
+    __syncthreads();
+    if (kk + KC < k0) fetch(kk + KC);
+#pragma unroll 4
+    for (int k = 0; k < KC; ++k) {
+      const T a = Lr[k * NB + r], d = Pc[k * NB + r];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const T pc = Pc[k * NB + q * 16 + c];
+        acc[c] -= a * pc;
+        dac[c] -= d * pc;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    Tt[q * 16 + c][r] = acc[c];
+    Dd[q * 16 + c][r] = dac[c];
+  }
+  __syncthreads();
+  if (q == 0) {
+    T rowv[NB];
+    StaticFor<0, NB>::Run([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      rowv[c] = r >= c ? Dd[c][r] : T(0);
+    });
+    const bool bad = CholRows(rowv, r);
+    if (bad && r == 0) *flag = 1;
+    // L11 for the substitution, [j][k] with the k run of one j contiguous (lane r holds row r;
+    // rows beyond kb are identity rows by the padding of D)
+    StaticFor<0, NB>::Run([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
+      buf[r * NB + c] = rowv[c];  // zero above the diagonal by construction
+      if (blockIdx.x == 0 && r < kb && c < kb && r >= c) W[(k0 + r) + (k0 + c) * ld] = rowv[c];
+    });
+  }
+  __syncthreads();
+  if (q == 0 && row0 < n) {
 #pragma unroll 1
     for (int jb = 0; jb < NB; jb += 8) {
       T tv[8];
@@ -474,11 +593,17 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
         const int64_t rem = n - (k0 + kb);
         const unsigned blocks = static_cast<unsigned>((rem + NB - 1) / NB);
         if (dt == F32) {
-          hipLaunchKernelGGL(PotrfDiagStepKernel<float>, dim3(1), dim3(256), 0, s, W.as<float>(), ld,
-                             K0, k0, kb, flag);
-          if (blocks)
-            hipLaunchKernelGGL(PotrfPanelStepKernel<float>, dim3(blocks), dim3(256), 0, s,
-                               W.as<float>(), ld, n, K0, k0, kb);
+          static const bool two_kernels = std::getenv("EPSILON_HIP_POTRF_TWO_KERNELS") != nullptr;
+          if (!two_kernels) {
+            hipLaunchKernelGGL(PotrfFusedStepKernel, dim3(blocks ? blocks : 1), dim3(256), 0, s,
+                               W.as<float>(), ld, n, K0, k0, kb, flag);
+          } else {
+            hipLaunchKernelGGL(PotrfDiagStepKernel<float>, dim3(1), dim3(256), 0, s, W.as<float>(), ld,
+                               K0, k0, kb, flag);
+            if (blocks)
+              hipLaunchKernelGGL(PotrfPanelStepKernel<float>, dim3(blocks), dim3(256), 0, s,
+                                 W.as<float>(), ld, n, K0, k0, kb);
+          }
         } else {
           hipLaunchKernelGGL(PotrfDiagStepKernel<double>, dim3(1), dim3(256), 0, s, W.as<double>(),
                              ld, K0, k0, kb, flag);

@@ -279,9 +279,9 @@ std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Inverse() const {
 std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::InverseDistributed() const {
   Comm* comm = Runtime::Get().comm();
   const int64_t nn = n();
-  // measured at n = 1e4 (tools_microbench.py): whole inverse 26.5 ms; a 1/8 slab of columns
-  // 24.6 ms, a quarter 27.2 ms, a half 31.5 ms - the Cholesky (16 ms) is the common part, so
-  // with the all-gather on top the split no longer pays on one node.  Kept (and tested) for
+  // measured at n = 1e4 (tools_microbench.py): whole inverse 23.9 ms; a 1/8 slab of columns
+  // 19.7 ms, a quarter 22.3 ms, a half 27.5 ms - the Cholesky (13.3 ms) is the common part, so
+  // with the all-gather on top the split is marginal on one node.  Kept (and tested) for
   // larger blocks / more ranks: EPSILON_HIP_DIST_INVERSE=<min ranks> turns it on (tests use 2).
   int min_ranks = 16;
   if (const char* e = std::getenv("EPSILON_HIP_DIST_INVERSE")) min_ranks = std::atoi(e);
