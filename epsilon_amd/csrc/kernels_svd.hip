@@ -287,7 +287,9 @@ template <class T> bool SmallJacobiSvd(const DVec& W, int64_t m, int64_t n, cons
   threads = std::max(64, std::min(threads, kSmallThreads));
   const int64_t need = (std::max(m, n) + G - 1) / G;
   if (need <= 8) return LaunchSmallJacobi<T, 8>(W, m, n, V, max_sweeps, tol, warm, bytes, G, threads, sweeps);
-  if (need <= 16) return LaunchSmallJacobi<T, 16>(W, m, n, V, max_sweeps, tol, warm, bytes, G, threads, sweeps);
+  if constexpr (sizeof(T) == 4) {  // 4 x 16 doubles per lane would spill
+    if (need <= 16) return LaunchSmallJacobi<T, 16>(W, m, n, V, max_sweeps, tol, warm, bytes, G, threads, sweeps);
+  }
   return LaunchSmallJacobi<T, 0>(W, m, n, V, max_sweeps, tol, warm, bytes, G, threads, sweeps);
 }
 
