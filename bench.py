@@ -152,12 +152,40 @@ def main():
     if sharded:
         from epsilon_amd import dist as edist
         cols = edist.column_range(n, rank, world)
-        edist.init_comm(rank, world, backend=args.comm)
-        # RCCL connects lazily on the first collective: do that (and a 100 MB one, the size class
-        # of the Gram all-reduce) before anything is timed
-        _solve.comm_warmup(1 << 16)
-        if args.comm == "rccl":
-            _solve.comm_warmup(25 * (1 << 20))
+        comm_used = args.comm
+        if args.comm == "rccl" and world > 1:
+            # every rank must be able to load RCCL through the library's own binding, or none
+            # uses it (a rank that fails alone would leave the others waiting in the init)
+            try:
+                _solve.comm_unique_id()
+                ok = 1
+            except Exception as e:
+                print("rank %d: cannot bind RCCL (%s)" % (rank, e), file=sys.stderr, flush=True)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                args.comm = "host"
+                comm_used = "host-staged fallback (torch.distributed all_reduce)"
+        try:
+            edist.init_comm(rank, world, backend=args.comm)
+            # RCCL connects lazily on the first collective: do that (and a 100 MB one, the size
+            # class of the Gram all-reduce) before anything is timed
+            _solve.comm_warmup(1 << 16)
+            if args.comm == "rccl":
+                _solve.comm_warmup(25 * (1 << 20))
+        except Exception as e:  # the library's own RCCL binding failed: say so, keep measuring
+            if args.comm != "rccl":
+                raise
+            print("rank %d: RCCL communicator failed (%s); falling back to collectives staged "
+                  "through torch.distributed" % (rank, e), file=sys.stderr, flush=True)
+            try:
+                _solve.comm_shutdown()
+            except Exception:
+                pass
+            edist.init_comm(rank, world, backend="host")
+            _solve.comm_warmup(1 << 16)
+            comm_used = "host-staged fallback (torch.distributed all_reduce)"
     else:
         cols = None
     At, b, lam = make_instance(m, n, device, cols=cols)
@@ -308,7 +336,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "lasso m=%d n=%d dense %s, PROX_ADMM, x0 density 0.01" % (m, n, args.dtype),
-                   "parallelism": "1 GPU" if world == 1 else "column-sharded x%d, 1 all-reduce/sweep" % world},
+                   "parallelism": "1 GPU" if world == 1 else "column-sharded x%d, 1 all-reduce/sweep" % world,
+                   **({"comm": comm_used} if sharded else {})},
         "roofline": roofline,
         "sweep": {"algorithmic_bytes_per_sweep_per_gpu": sweep_bytes,
                   "achieved_GBs": sweep_bytes / (ms_per_step * 1e-3) / 1e9,
