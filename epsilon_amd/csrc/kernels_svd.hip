@@ -537,7 +537,9 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
   for (int64_t i = 0; i < nb; ++i) block_at[i] = static_cast<int32_t>(i);
   const int64_t steps = nb - 1;
   static const char* inner_env = std::getenv("EPSILON_HIP_SVD_INNER");  // tuning knob
-  const int inner = inner_env && std::atoi(inner_env) > 0 ? std::atoi(inner_env) : 2;
+  // one inner sweep per step: measured 7-18 % faster than two, cold and warm-started, at n = 2048
+  // and 4096 (three is slower still); the outer iteration absorbs what an inner sweep leaves
+  const int inner = inner_env && std::atoi(inner_env) > 0 ? std::atoi(inner_env) : 1;
   int sweeps = 0;
   float prev_mx = 1e30f;
   for (; sweeps < max_sweeps; ++sweeps) {
