@@ -465,6 +465,54 @@ __global__ __launch_bounds__(kBlock) void PermuteBlocksKernel(T* __restrict__ ds
     d[i] = s[i];
 }
 
+// Partial Gram matrices of a step: G[split][pair] = P^T P over the row chunk `split` of the
+// 64-column pair.  Same reasoning as PanelUpdateKernel: a 64 x 64 result per pair wastes three
+// quarters of a 128 x 128 MFMA tile.  A workgroup streams its row chunk through LDS in tiles of
+// 128 rows; a thread owns a 4 x 4 block of the result.
+template <class T>
+__global__ __launch_bounds__(kBlock) void PanelGramKernel(const T* __restrict__ W, int64_t rows,
+                                                          int64_t chunk, int64_t h,
+                                                          T* __restrict__ G) {
+  constexpr int TR = 128, LD = TR + 1;
+  __shared__ T Ts[kJN * LD];  // [column][row]
+  const int t = threadIdx.x;
+  const int64_t pair = blockIdx.y, split = blockIdx.x;
+  const int64_t r0 = split * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  const T* src = W + pair * kJN * rows;
+  const int a0 = (t & 15) * 4, b0 = (t >> 4) * 4;
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
+  for (int64_t rt = r0; rt < r1; rt += TR) {
+    __syncthreads();
+    for (int idx = t; idx < TR * kJN; idx += kBlock) {
+      const int r = idx % TR, c = idx / TR;
+      Ts[c * LD + r] = (rt + r < r1) ? src[(rt + r) + static_cast<int64_t>(c) * rows] : T(0);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < TR; ++r) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[i] = Ts[(a0 + i) * LD + r];
+        bv[i] = Ts[(b0 + i) * LD + r];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+  }
+  T* g = G + (split * h + pair) * kJN * kJN;  // column-major 64 x 64
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[(a0 + i) + (b0 + j) * kJN] = acc[i][j];
+}
+
 // The update of a step, P_k <- P_k J_k for every pair k, with the round-robin move of the
 // panels folded in: thread = one row of a 64-column pair (64 inputs in registers, J_k broadcast
 // from LDS, 16 outputs at a time), written straight to where the two panels go next.  The
@@ -588,8 +636,13 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
     for (int64_t step = 0; step < steps; ++step) {
       // partial Grams in one launch: batch index = split * h + pair, split sp covers rows
       // [sp * kchunk, (sp + 1) * kchunk) of the panels (the last chunk is padded with zero rows)
-      GemmBatched(true, false, kJN, kJN, kchunk, 1.0, Wp, mp, kJN * mp, Wp, mp, kJN * mp, 0.0, G,
-                  kJN, kJN * kJN, h, false, nsplit, kchunk, kchunk);
+      if (mp >= 3072) {
+        const dim3 gg(static_cast<unsigned>(nsplit), static_cast<unsigned>(h));
+        hipLaunchKernelGGL(PanelGramKernel<T>, gg, dim3(kBlock), 0, s, Wp.as<T>(), mp, kchunk, h, G.as<T>());
+      } else {
+        GemmBatched(true, false, kJN, kJN, kchunk, 1.0, Wp, mp, kJN * mp, Wp, mp, kJN * mp, 0.0, G,
+                    kJN, kJN * kJN, h, false, nsplit, kchunk, kchunk);
+      }
       if (comm) comm->AllReduceSum(G);
       hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
                          G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
