@@ -316,9 +316,20 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
   // two LDS stages: slab k+1 is written while slab k is still being read, one barrier per slab
   __shared__ __attribute__((aligned(16))) float As[2][MK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][MK * LDB];
-  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
-  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * MT;
-  if (lower_only && i0 + MT <= j0) return;
+  int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
+  int64_t j0 = static_cast<int64_t>(blockIdx.y) * MT;
+  if (lower_only == 2) {
+    // compact 1-D grid over the tiles on and below the diagonal (no empty workgroups, and the
+    // round-robin of workgroups over the 8 XCDs splits the real tiles evenly)
+    const int64_t lin = blockIdx.x;
+    int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+    while (I * (I + 1) / 2 > lin) --I;
+    i0 = I * MT;
+    j0 = (lin - I * (I + 1) / 2) * MT;
+  } else if (lower_only && i0 + MT <= j0) {
+    return;
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wi = wave & 1, wj = wave >> 1;
@@ -520,7 +531,13 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                          reinterpret_cast<uintptr_t>(B.data()) % 16 == 0;
     if (aligned && mode != 3) {
       const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
-      const int lo = lower_only ? 1 : 0;
+      int lo = lower_only ? 1 : 0;
+      static const bool compact = std::getenv("EPSILON_HIP_SYRK_2D") == nullptr;
+      if (lower_only && batch == 1 && compact) {
+        const int64_t T = (M + MT - 1) / MT;
+        grid = dim3(static_cast<unsigned>(T * (T + 1) / 2), 1, 1);
+        lo = 2;
+      }
 #define EPS_PIPE(CA, CB)                                                                       \
   hipLaunchKernelGGL((GemmMfmaF32PipeKernel<CA, CB>), grid, dim3(kBlock), 0, s, M, N, K, al,    \
                      A.as<float>(), lda, B.as<float>(), ldb, be, C.as<float>(), ldc, lo, sA, sB, sC, n1, sA2, sB2)
