@@ -345,11 +345,13 @@ class ProxADMMSolver final : public Solver {
     const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
     bool rhs_added = false;
     if (!from_state) {
-      // unsharded: the constant part of the rhs rides in the reduction kernel (same rounding
-      // order as the separate axpy: sum first, then + rhs)
-      const bool fold = !sharded && f.ls.rhs_arg.n != 0;
+      // the constant part of the rhs rides in the reduction kernel (same rounding order as the
+      // separate axpy: sum first, then + rhs); in a sharded run rank 0 alone contributes it to
+      // the sum over ranks - one launch less in a sweep that is launch-latency-bound at N = 8
+      const bool have_rhs = f.ls.rhs_arg.n != 0;
+      const bool fold = have_rhs && (!sharded || Runtime::Get().comm()->rank() == 0);
       k::ReducePartials(f.m, f.grid, f.tpart, -L.scale(), 0.0, f.p, fold ? &f.ls.rhs_arg : nullptr);
-      rhs_added = fold;
+      rhs_added = have_rhs;  // folded here, or by rank 0 into the all-reduced sum
     }
     if (sharded) Runtime::Get().comm()->AllReduceSum(f.p);
     if (f.ls.rhs_arg.n != 0 && !rhs_added) k::Axpby(f.p, 1.0, f.ls.rhs_arg, 1.0);
