@@ -162,8 +162,8 @@ class Solver(object):
 
     def __init__(self, problem_bytes, solver_params_bytes, data):
         L = lib()
-        self._keep = []
-        blobs, nb = _blobs(data, self._keep)
+        keep = []  # host blobs are copied by the library: nothing to keep alive after the call
+        blobs, nb = _blobs(data, keep)
         self._h = ctypes.c_void_p()
         _check(L.eps_solver_create(problem_bytes, ctypes.c_size_t(len(problem_bytes)),
                                    solver_params_bytes,
@@ -173,7 +173,6 @@ class Solver(object):
     def set_parameter(self, parameter_id, constant_bytes, data=None):
         keep = []
         blobs, nb = _blobs(data or {}, keep)
-        self._keep.extend(keep)
         _check(lib().eps_solver_set_parameter(self._h, parameter_id.encode(), constant_bytes,
                                               ctypes.c_size_t(len(constant_bytes)), blobs,
                                               ctypes.c_size_t(nb)))

@@ -57,8 +57,9 @@ template <class F> int Guard(F f) {
   return 1;
 }
 
-std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType dt) {
-  auto dm = std::make_shared<DataMap>(dt);
+// own_host: copy host blobs (solver handles outlive the call that passes them; the one-shot entry
+// points read the caller's memory in place, it is theirs for the duration of the call).
+void InsertBlobs(DataMap* dm, const eps_blob* data, size_t ndata, bool own_host) {
   bool device_blobs = false;
   for (size_t i = 0; i < ndata; ++i) {
     EPS_CHECK_MSG(data[i].key != nullptr, "data blob without a key");
@@ -68,7 +69,8 @@ std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType d
     b.kind = data[i].kind;
     EPS_CHECK_MSG(b.kind >= 0 && b.kind <= 2, "bad blob kind " << b.kind);
     if (b.kind != 0) device_blobs = true;
-    dm->Insert(data[i].key, b);
+    if (own_host) dm->InsertOwned(data[i].key, b);
+    else dm->Insert(data[i].key, b);
   }
   // Borrowed device memory is read on this library's own non-blocking stream, which has no
   // ordering with whatever stream produced it: wait for the device once, here.
@@ -76,6 +78,12 @@ std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType d
     Runtime::Get();
     EPS_HIP(hipDeviceSynchronize());
   }
+}
+
+std::shared_ptr<DataMap> MakeDataMap(const eps_blob* data, size_t ndata, DType dt,
+                                     bool own_host = false) {
+  auto dm = std::make_shared<DataMap>(dt);
+  InsertBlobs(dm.get(), data, ndata, own_host);
   return dm;
 }
 
@@ -215,7 +223,7 @@ int eps_solver_create(const void* problem, size_t problem_len, const void* solve
     SetCurrentDType(dt);
     std::unique_ptr<eps_solver> s(new eps_solver);
     s->dtype = dt;
-    s->data = MakeDataMap(data, ndata, dt);
+    s->data = MakeDataMap(data, ndata, dt, /*own_host=*/true);
     s->solver = CreateSolver(pb::ParseProblem(problem, problem_len), s->data,
                              pb::ParseSolverParams(solver_params, solver_params_len));
     s->solver->set_log(LogToStdout);
@@ -227,13 +235,7 @@ int eps_solver_set_parameter(eps_solver* s, const char* id, const void* constant
                              size_t len, const eps_blob* data, size_t ndata) {
   return Guard([&] {
     EPS_CHECK(s != nullptr && id != nullptr);
-    for (size_t i = 0; i < ndata; ++i) {
-      Blob b;
-      b.ptr = data[i].ptr;
-      b.len = data[i].len;
-      b.kind = data[i].kind;
-      s->data->Insert(data[i].key, b);
-    }
+    InsertBlobs(s->data.get(), data, ndata, /*own_host=*/true);
     s->data->SetParameter(id, pb::ParseConstant(constant_proto, len));
   });
 }

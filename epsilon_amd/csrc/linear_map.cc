@@ -51,6 +51,16 @@ OpCacheScope::~OpCacheScope() { g_op_cache = saved; }
 
 // ---- DataMap --------------------------------------------------------------------------------------
 
+void DataMap::InsertOwned(const std::string& key, Blob b) {
+  if (b.kind == 0 && b.len > 0) {
+    EPS_CHECK_MSG(b.ptr != nullptr, "host blob '" << key << "' has a null pointer");
+    const char* src = static_cast<const char*>(b.ptr);
+    b.owned = std::make_shared<std::vector<char>>(src, src + b.len);
+    b.ptr = b.owned->data();
+  }
+  Insert(key, b);
+}
+
 const Blob& DataMap::Get(const std::string& key) const {
   auto it = blobs_.find(key);
   EPS_CHECK_MSG(it != blobs_.end(), "data location '" << key << "' not in data map");
@@ -81,6 +91,13 @@ DVec DataMap::DenseDevice(const pb::Constant& c_in) {
                   "dense blob '" << c.data_location << "' has " << b.len << " bytes, expected "
                                  << count * sizeof(double));
     v = DVec::FromHost(static_cast<const double*>(b.ptr), count, dtype_);
+    // a large owned copy has served its purpose once the matrix is resident in HBM
+    // (DenseHost falls back to the device copy)
+    if (b.owned && b.len >= (64u << 20)) {  // (FromHost has synchronised)
+      Blob& mb = blobs_[c.data_location];
+      mb.owned.reset();
+      mb.ptr = nullptr;
+    }
   } else {
     const DType bdt = b.kind == 1 ? F32 : F64;
     EPS_CHECK_MSG(b.len == static_cast<size_t>(count),
@@ -104,7 +121,11 @@ uint64_t DataMap::DenseId(const pb::Constant& c_in) const {
   if (c.data_location.empty()) return 0;
   const Blob& b = Get(c.data_location);
   uint64_t h = HashBytes(c.data_location.data(), c.data_location.size(), 0x5eed);
-  h = HashCombine(h, reinterpret_cast<uintptr_t>(b.ptr));
+  // owned host copies are identified by (key, generation): their address means nothing and
+  // re-binding the key must miss; borrowed memory by its address as well
+  if (b.kind != 0) h = HashCombine(h, reinterpret_cast<uintptr_t>(b.ptr));
+  auto g = generation_.find(c.data_location);
+  h = HashCombine(h, g == generation_.end() ? 0 : g->second);
   h = HashCombine(h, b.len);
   h = HashCombine(h, static_cast<uint64_t>(c.m) << 32 | static_cast<uint32_t>(c.n));
   return h ? h : 1;
@@ -115,7 +136,7 @@ std::vector<double> DataMap::DenseHost(const pb::Constant& c_in) {
   EPS_CHECK_MSG(c.constant_type == pb::Constant::DENSE_MATRIX, "constant is not a dense matrix");
   const int64_t count = static_cast<int64_t>(c.m) * c.n;
   const Blob& b = Get(c.data_location);
-  if (b.kind == 0) {
+  if (b.kind == 0 && b.ptr != nullptr) {
     EPS_CHECK(b.len == static_cast<size_t>(count) * sizeof(double));
     std::vector<double> out(count);
     std::memcpy(out.data(), b.ptr, b.len);

@@ -60,6 +60,9 @@ struct Blob {
   const void* ptr = nullptr;
   size_t len = 0;   // bytes for host blobs, element count for device blobs
   int kind = 0;     // 0 host bytes, 1 device f32, 2 device f64
+  // Host blobs of a solver handle are COPIED at the boundary, as the reference copies every
+  // blob into its DataMap (python/epopt/solvemodule.cc:58-72): `ptr` then points into `owned`.
+  std::shared_ptr<std::vector<char>> owned;
 };
 
 // Data map {location -> blob} plus a cache of what was already uploaded, so one constant is
@@ -68,7 +71,15 @@ class DataMap {
  public:
   explicit DataMap(DType dt) : dtype_(dt) {}
   DType dtype() const { return dtype_; }
-  void Insert(const std::string& key, const Blob& b) { blobs_[key] = b; }
+  // (Re)binds a location.  A device copy made from the previous blob under this key is dropped
+  // and the key's generation is bumped, so content ids (OpCache) of the old data never match.
+  void Insert(const std::string& key, const Blob& b) {
+    blobs_[key] = b;
+    uploaded_.erase(key);
+    ++generation_[key];
+  }
+  // Same, after copying a host blob's bytes (device blobs stay borrowed).
+  void InsertOwned(const std::string& key, Blob b);
   bool Has(const std::string& key) const { return blobs_.count(key) != 0; }
   const Blob& Get(const std::string& key) const;
   // Dense constant as a device vector of m*n entries (column-major), compute dtype.
@@ -85,6 +96,7 @@ class DataMap {
   DType dtype_;
   std::map<std::string, Blob> blobs_;
   std::map<std::string, DVec> uploaded_;
+  std::map<std::string, uint64_t> generation_;
   std::map<std::string, pb::Constant> params_;
 };
 

@@ -44,7 +44,10 @@ enum {
 };
 typedef struct eps_blob {
   const char* key;  /* NUL-terminated location / variable id */
-  const void* ptr;  /* borrowed for the duration of the call (device blobs: of the solver) */
+  const void* ptr;  /* host: read during the call only - the solver-handle entry points copy the
+                     * bytes, as the reference copies every blob (solvemodule.cc:58-72), so the
+                     * caller may free or overwrite them as soon as the call returns;
+                     * device: borrowed while a solver handle built from it exists */
   size_t len;
   int kind;
 } eps_blob;
@@ -99,7 +102,10 @@ void eps_result_free(eps_result* r);
 /* ---- solver handles: warm start, staged runs, timing --------------------------------------- */
 /* Replaces the process-global warm-start cache (solvemodule.cc:22,142-156): the caller keeps the
  * handle, so the data matrix, the cached factorisation and x/y/u stay resident in HBM across
- * calls.  Host blobs are consumed during create/init; device blobs are borrowed until destroy. */
+ * calls.  Host blobs are copied by create / set_parameter (free them when the call returns; a
+ * copy of 64 MB or more is released again once the matrix is resident in HBM); device blobs are
+ * borrowed until destroy.  Re-binding a location that is already bound replaces its contents:
+ * the next eps_solver_init rebuilds everything that depended on it. */
 int eps_solver_create(const void* problem, size_t problem_len, const void* solver_params,
                       size_t solver_params_len, const eps_blob* data, size_t ndata,
                       eps_solver** out);
