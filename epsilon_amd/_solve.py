@@ -241,6 +241,15 @@ def comm_warmup(count=1 << 20):
     _check(lib().eps_comm_warmup(ctypes.c_size_t(count)))
 
 
+def comm_enable_peer(slot_floats=0, rehearse_ranks=0):
+    """Collective: set up the one-shot peer-write window (include/epsilon_hip.h).  Returns
+    (enabled, reason-if-not)."""
+    on = ctypes.c_int(0)
+    _check(lib().eps_comm_enable_peer(ctypes.c_size_t(slot_floats), ctypes.c_int(rehearse_ranks),
+                                      ctypes.byref(on)))
+    return bool(on.value), ("" if on.value else lib().eps_last_error().decode("utf-8", "replace"))
+
+
 def comm_shutdown():
     _check(lib().eps_comm_shutdown())
     del _comm_keep[:]

@@ -22,6 +22,7 @@ HOST_SOURCES = ["wire.cc", "device.cc", "comm.cc", "linear_map.cc", "sparse.cc",
 DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_prox.hip", ["-ffp-contract=off"]),
                   ("kernels_fused.hip", ["-ffp-contract=off"]),
+                  ("kernels_peer.hip", ["-ffp-contract=off"]),
                   ("kernels_gemv.hip", []),
                   ("kernels_gemv_multi.hip", []),
                   ("kernels_gemm.hip", []),

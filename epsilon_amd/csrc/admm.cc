@@ -104,9 +104,20 @@ int Solver::Run(int max_sweeps) {
   SetCurrentDType(data_->dtype());
   const double t0 = Now();
   int done = 0;
+  const int epoch = params_.epoch_iterations > 0 ? params_.epoch_iterations : 1;
+  const int log_every = params_.log_iterations > 0 ? params_.log_iterations : 1;
   while (!finished_ && iter_ < params_.max_iterations && (max_sweeps < 0 || done < max_sweeps)) {
-    Sweep();
-    ++done;
+    // the sweeps up to and including the next one that is followed by a host decision (residual
+    // check; log line when verbose) are enqueued as one batch
+    int batch = 1;
+    while ((iter_ + batch - 1) % epoch != 0 &&
+           !(params_.verbose && (iter_ + batch - 1) % log_every == 0))
+      ++batch;
+    if (batch > params_.max_iterations - iter_) batch = params_.max_iterations - iter_;
+    if (max_sweeps >= 0 && batch > max_sweeps - done) batch = max_sweeps - done;
+    SweepBatch(batch);
+    done += batch;
+    iter_ += batch - 1;  // index of the last sweep of the batch
     if (iter_ % params_.epoch_iterations == 0) {
       ComputeResiduals();
       if (status_.state == pb::SolverStatus::OPTIMAL) {
@@ -123,6 +134,7 @@ int Solver::Run(int max_sweeps) {
     finished_ = true;
   }
   Runtime::Get().Sync();
+  if (Runtime::Get().peer()) Runtime::Get().peer()->CheckError();
   loop_seconds_ += Now() - t0;
   if (finished_) LogStatus();
   status_.init_time = init_seconds_;
@@ -145,6 +157,7 @@ void Solver::Solve() {
 class ProxADMMSolver final : public Solver {
  public:
   using Solver::Solver;
+  ~ProxADMMSolver() override { ResetGraph(); }
 
   void Init() override {  // :110-129
     SetCurrentDType(data_->dtype());
@@ -264,6 +277,7 @@ class ProxADMMSolver final : public Solver {
   // reduction (+ the all-reduce when sharded) and the apply of the cached inverse.
   void TryEnableFused() {
     fused_ = false;
+    ResetGraph();
     const char* env = std::getenv("EPSILON_HIP_FUSED");
     if (env && env[0] == '0') return;
     if (data_->dtype() != F32 || N_ != 2 || problem_.constraint.size() != 1) return;
@@ -305,12 +319,31 @@ class ProxADMMSolver final : public Solver {
     f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
     {
       Comm* comm = Runtime::Get().comm();
-      const int G = comm ? comm->size() : 1;
+      PeerExchange* px = Runtime::Get().peer();
+      const ShardSpec& sh = ShardSpec::Get();
+      const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
+      // one-shot peer-write exchange inside the sweep's own kernels (kernels_peer.hip) when the
+      // ranks share a window and the m-float message fits its slots; RCCL collectives otherwise
+      f.use_peer = sharded && px != nullptr && f.m <= px->slot() && f.ls.Dinv_arg != nullptr &&
+                   !f.ls.Dinv_arg->trans() && f.ls.Dinv_arg->rows() == f.m;
+      const int G = f.use_peer ? px->view().G : (comm ? comm->size() : 1);
       f.slab = ((f.m + G - 1) / G + 3) / 4 * 4;
       f.wpad = DVec::Zeros(f.slab * G, dt);
       f.wslice = DVec::Zeros(f.slab, dt);
       f.w = f.wpad.Slice(0, f.m);  // the gathered vector IS w (first m entries)
+      // the inverse is applied by row slabs + all-gather from 3 ranks up; with 2 ranks the
+      // symmetric apply of the whole matrix reads the same m^2/2 entries and needs no exchange
+      const char* e = std::getenv("EPSILON_HIP_SHARDED_APPLY");
+      const bool want_slab = e ? e[0] != 'r' : G >= 3;
+      f.peer_slab = f.use_peer && want_slab &&
+                    k::PeerSlabApplySupported(px->view(), f.m, f.slab, f.ls.Dinv_arg->data(), f.m);
     }
+    {
+      const DenseMatrixImpl& D = *f.ls.Dinv_arg;
+      if (D.symmetric() && D.rows() == f.m && D.rows() >= 1024 && !D.trans())
+        f.symv_work = DVec::Empty(k::SymvWorkspace(f.m), dt);
+    }
+    ResetGraph();
     fs_ = f;
     // the generic containers become views of the fused state
     x_[0] = BlockVector();
@@ -381,8 +414,81 @@ class ProxADMMSolver final : public Solver {
       comm->AllGather(mine.data(), f.wpad.data(), static_cast<size_t>(per), F32);
       (void)G;
     } else {
-      D.Apply(1.0, f.p, 0.0, f.w);
+      ApplyInverseFixed();
     }
+  }
+
+  // The sharded sweep's tail on the peer window: 2 launches, no collective call.
+  void FusedForwardPeer() {
+    FusedState& f = fs_;
+    const DenseMatrixImpl& L = *f.ls.L_arg_var;
+    const DenseMatrixImpl& D = *f.ls.Dinv_arg;
+    const PeerView& pv = Runtime::Get().peer()->view();
+    k::PeerReduceExchange(pv, f.m, f.grid, f.tpart, -L.scale(),
+                          f.ls.rhs_arg.n != 0 ? &f.ls.rhs_arg : nullptr, f.p);
+    if (f.peer_slab) {
+      const int64_t lo = std::min<int64_t>(f.m, static_cast<int64_t>(pv.rank) * f.slab);
+      k::PeerSlabApplyExchange(pv, f.m, f.slab, lo, D.data(), f.m, D.scale(), f.p, f.wpad);
+    } else {
+      ApplyInverseFixed();
+    }
+  }
+
+  // w = Dinv p with every buffer at a fixed address (what a captured launch needs)
+  void ApplyInverseFixed() {
+    FusedState& f = fs_;
+    const DenseMatrixImpl& D = *f.ls.Dinv_arg;
+    if (f.symv_work.n > 0) k::Symv(f.m, D.scale(), D.data(), f.m, f.p, 0.0, f.w, &f.symv_work);
+    else D.Apply(1.0, f.p, 0.0, f.w);
+  }
+
+  void ResetGraph() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    graph_exec_ = nullptr;
+    graph_ = nullptr;
+    graph_len_ = 0;
+  }
+
+  // The sweeps between two residual checks replayed from one hipGraph: a sharded sweep is 3
+  // short dependent launches (~60 us of kernels at 8 ranks), so the host's per-launch cost and
+  // jitter would otherwise sit on the critical path.  Iterates are bit-identical to the eager
+  // launches (same kernels, same arguments; the exchange tags come from a device counter).
+  void SweepBatch(int count) override {
+    static const int mode = [] {  // EPSILON_HIP_GRAPH: 0 never, 1 always (fused), default: peer mode
+      const char* e = std::getenv("EPSILON_HIP_GRAPH");
+      return e ? std::atoi(e) : -1;
+    }();
+    Runtime& rt = Runtime::Get();
+    const ShardSpec& sh = ShardSpec::Get();
+    const bool rccl_in_sweep = fused_ && !fs_.use_peer && sh.active() && sh.IsSharded(fs_.ls.var_key);
+    const bool fixed_buffers = (fs_.use_peer && fs_.peer_slab) || fs_.symv_work.n > 0;
+    const bool want = fused_ && !rccl_in_sweep && fixed_buffers &&
+                      (mode == 1 || (mode != 0 && fs_.use_peer));
+    if (!want || count < 2 || rt.profiling()) {
+      for (int i = 0; i < count; ++i) Sweep();
+      return;
+    }
+    if (graph_exec_ == nullptr || graph_len_ != count) {
+      ResetGraph();
+      hipStream_t s = rt.stream();
+      EPS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rt.set_capturing(true);
+      try {
+        for (int i = 0; i < count; ++i) FusedSweep();
+      } catch (...) {
+        rt.set_capturing(false);
+        hipGraph_t dead = nullptr;
+        (void)hipStreamEndCapture(s, &dead);
+        if (dead) (void)hipGraphDestroy(dead);
+        throw;
+      }
+      rt.set_capturing(false);
+      EPS_HIP(hipStreamEndCapture(s, &graph_));
+      EPS_HIP(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+      graph_len_ = count;
+    }
+    EPS_HIP(hipGraphLaunch(graph_exec_, rt.stream()));
   }
 
   void FusedSweep() {
@@ -409,6 +515,12 @@ class ProxADMMSolver final : public Solver {
     a.y1 = f.y1;
     a.y1prev = f.y1prev;
     a.tpart = f.tpart;
+    if (f.use_peer) {
+      a.epoch = Runtime::Get().peer()->view().epoch;
+      k::LassoFusedPass(a);
+      FusedForwardPeer();
+      return;
+    }
     k::LassoFusedPass(a);
     FusedForward(/*from_state=*/false);
   }
@@ -452,6 +564,7 @@ class ProxADMMSolver final : public Solver {
     }
     const int s_u = (AT_ * u_).NormSqAsync();
     rt.FetchSlots();
+    if (rt.peer()) rt.peer()->CheckError();
 
     double max_norm = std::sqrt(rt.SlotValue(s_b));
     double own_max = -1;
@@ -492,10 +605,16 @@ class ProxADMMSolver final : public Solver {
     int64_t m = 0, n = 0;
     int grid = 0;
     int64_t slab = 0;  // rows of the cached inverse applied per rank (sharded runs)
+    bool use_peer = false;   // exchanges ride in the sweep's kernels (peer window), not in RCCL
+    bool peer_slab = false;  // ... and the inverse is applied by row slabs
     DVec u, x0, x1, y0, y1, y1prev, w, p, tpart, wpad, wslice;
+    DVec symv_work;  // fixed workspace of the symmetric inverse apply (empty: not that form)
   };
   bool fused_ = false;
   FusedState fs_;
+  hipGraph_t graph_ = nullptr;
+  hipGraphExec_t graph_exec_ = nullptr;
+  int graph_len_ = 0;
   BlockVector u_;
   std::vector<BlockVector> x_, y_, y_prev_;
 };

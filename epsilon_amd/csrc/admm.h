@@ -47,6 +47,11 @@ class Solver {
 
  protected:
   virtual void Sweep() = 0;
+  // `count` sweeps with no host decision in between (Run() cuts the iteration into such runs at
+  // the residual checks); a driver whose sweep is launch-bound replays them from a hipGraph.
+  virtual void SweepBatch(int count) {
+    for (int i = 0; i < count; ++i) Sweep();
+  }
   virtual void ComputeResiduals() = 0;
   void LogStatus();
   void FinishResiduals(double r2, double s2, double eps_pri, double eps_dual);

@@ -293,6 +293,8 @@ int eps_comm_init_rccl(int rank, int world, const void* id128) {
   return Guard([&] {
     EPS_CHECK(id128 != nullptr && world >= 1 && rank >= 0 && rank < world);
     Runtime& rt = Runtime::Get();
+    delete rt.peer();
+    rt.set_peer(nullptr);
     delete rt.comm();
     rt.set_comm(nullptr);
     rt.set_comm(NewRcclComm(rank, world, id128));
@@ -303,6 +305,8 @@ int eps_comm_init_callback(int rank, int world, eps_allreduce_fn fn, void* ctx) 
   return Guard([&] {
     EPS_CHECK(fn != nullptr && world >= 1 && rank >= 0 && rank < world);
     Runtime& rt = Runtime::Get();
+    delete rt.peer();
+    rt.set_peer(nullptr);
     delete rt.comm();
     rt.set_comm(nullptr);
     rt.set_comm(NewHostCallbackComm(rank, world, fn, ctx));
@@ -328,10 +332,32 @@ int eps_comm_warmup(size_t count) {
   });
 }
 
+int eps_comm_enable_peer(size_t slot_floats, int rehearse_ranks, int* enabled) {
+  return Guard([&] {
+    Runtime& rt = Runtime::Get();
+    EPS_CHECK_MSG(rt.comm() != nullptr, "eps_comm_enable_peer: no communicator");
+    if (enabled) *enabled = 0;
+    rt.Sync();
+    delete rt.peer();
+    rt.set_peer(nullptr);
+    std::string why;
+    PeerExchange* px = PeerExchange::Create(rt.comm(), static_cast<int64_t>(slot_floats ? slot_floats : 16384),
+                                            rehearse_ranks, &why);
+    if (px == nullptr) {
+      g_last_error = "peer window not available: " + why;  // informational: the call succeeds
+      return;
+    }
+    rt.set_peer(px);
+    if (enabled) *enabled = 1;
+  });
+}
+
 int eps_comm_shutdown(void) {
   return Guard([&] {
     Runtime& rt = Runtime::Get();
     rt.Sync();
+    delete rt.peer();
+    rt.set_peer(nullptr);
     delete rt.comm();
     rt.set_comm(nullptr);
     ShardSpec::Get().Clear();

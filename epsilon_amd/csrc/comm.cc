@@ -3,8 +3,12 @@
 #include <dlfcn.h>
 
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <vector>
+
+#include "kernels.h"
 
 namespace eps {
 
@@ -164,6 +168,201 @@ Comm* NewRcclComm(int rank, int size, const void* id128) { return new RcclComm(r
 
 Comm* NewHostCallbackComm(int rank, int size, HostAllReduceFn fn, void* ctx) {
   return new HostCallbackComm(rank, size, fn, ctx);
+}
+
+}  // namespace eps
+
+// ---- PeerExchange ----------------------------------------------------------------------------------
+
+namespace eps {
+
+namespace {
+
+// Window memory must be readable mid-kernel by a GPU other than the one that wrote it: take
+// uncached / fine-grained device memory when the runtime offers it (what RCCL does for its own
+// peer buffers), plain device memory otherwise (all accesses to it are system-scope anyway).
+void* AllocWindow(size_t bytes) {
+  void* p = nullptr;
+#ifdef hipDeviceMallocUncached
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess && p) return p;
+  (void)hipGetLastError();
+#endif
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess && p) return p;
+  (void)hipGetLastError();
+  EPS_HIP(hipMalloc(&p, bytes));
+  return p;
+}
+
+}  // namespace
+
+// true iff `ok` holds on every rank (collective)
+static bool AllRanksOk(Comm* comm, bool ok) {
+  const double bad = ok ? 0.0 : 1.0;
+  DVec d = DVec::FromHost(&bad, 1, F64);
+  comm->AllReduceSum(d);
+  return d.ToHost()[0] == 0.0;
+}
+
+PeerExchange* PeerExchange::Create(Comm* comm, int64_t slot_floats, int rehearse_ranks,
+                                   std::string* why) {
+  EPS_CHECK(comm != nullptr && slot_floats > 0);
+  Runtime& rt = Runtime::Get();
+  EPS_HIP(hipSetDevice(rt.device()));
+  const bool rehearse = rehearse_ranks > 1;
+  if (rehearse) EPS_CHECK_MSG(comm->size() == 1, "rank rehearsal needs a single-rank communicator");
+  const int G = rehearse ? rehearse_ranks : comm->size();
+  EPS_CHECK_MSG(G <= PeerView::kMaxPeers, "peer exchange supports at most " << PeerView::kMaxPeers
+                                                                            << " ranks, got " << G);
+  std::unique_ptr<PeerExchange> px(new PeerExchange());
+  PeerView& v = px->view_;
+  v.G = G;
+  v.rank = comm->rank();
+  v.rehearse = rehearse ? 1 : 0;
+  v.slot = (slot_floats + 63) / 64 * 64;
+  for (int q = 0; q < PeerView::kMaxPeers; ++q) v.win[q] = nullptr;
+  constexpr int HB = static_cast<int>(sizeof(hipIpcMemHandle_t));
+  const bool shared = !rehearse && comm->size() > 1;
+  std::vector<double> enc(HB, 0.0);
+  std::string err;
+  // step 1 (local): window, epoch counter, error word, IPC handle
+  try {
+    // [channel][source rank][slot] granules, then one 256-byte line for the epoch counter
+    const size_t granules = static_cast<size_t>(kChannels) * G * v.slot;
+    px->bytes_ = granules * sizeof(unsigned long long) + 256;
+    px->local_ = AllocWindow(px->bytes_);
+    EPS_HIP(hipMemset(px->local_, 0, px->bytes_));
+    v.epoch = reinterpret_cast<unsigned*>(static_cast<char*>(px->local_) +
+                                          granules * sizeof(unsigned long long));
+    EPS_HIP(hipHostMalloc(reinterpret_cast<void**>(&px->err_host_), 64, hipHostMallocMapped));
+    *px->err_host_ = 0;
+    void* err_dev = nullptr;
+    EPS_HIP(hipHostGetDevicePointer(&err_dev, px->err_host_, 0));
+    v.err = static_cast<unsigned*>(err_dev);
+    if (shared) {
+      hipIpcMemHandle_t mine;
+      EPS_HIP(hipIpcGetMemHandle(&mine, px->local_));
+      const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mine);
+      for (int i = 0; i < HB; ++i) enc[i] = mb[i];
+    }
+  } catch (const std::exception& e) {
+    err = e.what();
+    (void)hipGetLastError();
+  }
+  if (!shared) {
+    if (!err.empty()) {
+      if (why) *why = err;
+      return nullptr;
+    }
+    for (int q = 0; q < G; ++q) v.win[q] = static_cast<unsigned long long*>(px->local_);
+  } else {
+    // exchange the handles: one float per byte (exact under the sum-with-zeros all-gather of
+    // the host-callback backend, which would not preserve arbitrary bit patterns)
+    DVec send = DVec::FromHost(enc.data(), HB, F32);
+    DVec recv = DVec::Zeros(static_cast<int64_t>(HB) * G, F32);
+    comm->AllGather(send.data(), recv.data(), HB, F32);
+    rt.Sync();
+    if (!AllRanksOk(comm, err.empty())) {
+      if (why) *why = err.empty() ? "a peer rank could not create its window" : err;
+      return nullptr;
+    }
+    // step 2: map the peers' windows
+    try {
+      std::vector<double> all = recv.ToHost();
+      for (int q = 0; q < G; ++q) {
+        if (q == v.rank) {
+          v.win[q] = static_cast<unsigned long long*>(px->local_);
+          continue;
+        }
+        hipIpcMemHandle_t h;
+        unsigned char* hb = reinterpret_cast<unsigned char*>(&h);
+        for (int i = 0; i < HB; ++i)
+          hb[i] = static_cast<unsigned char>(all[static_cast<size_t>(q) * HB + i]);
+        void* p = nullptr;
+        EPS_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        px->opened_.push_back(p);
+        v.win[q] = static_cast<unsigned long long*>(p);
+      }
+    } catch (const std::exception& e) {
+      err = e.what();
+      (void)hipGetLastError();
+    }
+    if (!AllRanksOk(comm, err.empty())) {
+      if (why) *why = err.empty() ? "a peer rank could not map the windows" : err;
+      return nullptr;
+    }
+  }
+  // step 3: the exchange kernels on a known pattern, both channels
+  try {
+    px->SelfTest();
+  } catch (const std::exception& e) {
+    err = e.what();
+    (void)hipGetLastError();
+  }
+  if (!AllRanksOk(comm, err.empty())) {
+    if (why) *why = err.empty() ? "the self test failed on a peer rank" : err;
+    return nullptr;
+  }
+  return px.release();
+}
+
+PeerExchange::~PeerExchange() {
+  for (void* p : opened_) (void)hipIpcCloseMemHandle(p);
+  if (local_) (void)hipFree(local_);
+  if (err_host_) (void)hipHostFree(err_host_);
+}
+
+void PeerExchange::CheckError() {
+  if (err_host_ && *err_host_ != 0) {
+    const unsigned code = *err_host_;
+    *err_host_ = 0;
+    (void)hipMemset(view_.epoch + 16, 0, sizeof(unsigned));  // the device-side copy
+    EPS_FATAL("peer exchange: a poll timed out (code " << code
+                                                       << "): a peer rank did not deliver its part");
+  }
+}
+
+void PeerExchange::SelfTest() {
+  // all-reduce of (rank + 1) * (i % 7 + 1) over both code paths of the exchange kernels
+  Runtime& rt = Runtime::Get();
+  const int G = view_.G;
+  const int64_t n = std::min<int64_t>(view_.slot, 1000);
+  std::vector<double> h(n);
+  const int me = view_.rehearse ? 0 : view_.rank;
+  for (int64_t i = 0; i < n; ++i) h[i] = (me + 1.0) * static_cast<double>(i % 7 + 1);
+  DVec part = DVec::FromHost(h.data(), n, F32);
+  DVec out = DVec::Zeros(n, F32);
+  k::PeerBumpEpoch(view_);
+  k::PeerReduceExchange(view_, n, 1, part, 1.0, nullptr, out);
+  rt.Sync();
+  CheckError();
+  std::vector<double> got = out.ToHost();
+  double scale = 0;
+  for (int q = 0; q < G; ++q) scale += view_.rehearse ? 1.0 : q + 1.0;
+  for (int64_t i = 0; i < n; ++i)
+    EPS_CHECK_MSG(got[i] == scale * static_cast<double>(i % 7 + 1),
+                  "peer exchange self test: entry " << i << " is " << got[i] << ", expected "
+                                                    << scale * static_cast<double>(i % 7 + 1));
+  // channel 1: w = 2 * I p by slabs of 64 rows (the matrix is 2 I, so w = 2 p on every rank;
+  // in a rehearsal every slab holds rank 0's rows)
+  const int64_t slab = std::min<int64_t>(64, view_.slot), mt = slab * G;
+  std::vector<double> Dh(static_cast<size_t>(mt) * mt, 0.0), ph(mt);
+  for (int64_t i = 0; i < mt; ++i) {
+    Dh[static_cast<size_t>(i) * mt + i] = 2.0;
+    ph[i] = static_cast<double>(i % 11) - 5.0;
+  }
+  DVec D = DVec::FromHost(Dh.data(), mt * mt, F32);
+  DVec p = DVec::FromHost(ph.data(), mt, F32);
+  DVec w = DVec::Zeros(mt, F32);
+  k::PeerBumpEpoch(view_);
+  k::PeerSlabApplyExchange(view_, mt, slab, static_cast<int64_t>(me) * slab, D, mt, 1.0, p, w);
+  rt.Sync();
+  CheckError();
+  got = w.ToHost();
+  for (int64_t i = 0; i < mt; ++i) {
+    const double want = 2.0 * ph[view_.rehearse ? i % slab : i];
+    EPS_CHECK_MSG(got[i] == want, "peer exchange self test (slab apply): entry "
+                                      << i << " is " << got[i] << ", expected " << want);
+  }
 }
 
 }  // namespace eps

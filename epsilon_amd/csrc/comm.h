@@ -16,6 +16,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <vector>
 
 #include "device.h"
 
@@ -42,6 +43,56 @@ typedef void (*HostAllReduceFn)(void* host_buf, size_t count, int dtype, void* c
 void GetRcclUniqueId(void* out128);
 Comm* NewRcclComm(int rank, int size, const void* id128);
 Comm* NewHostCallbackComm(int rank, int size, HostAllReduceFn fn, void* ctx);
+
+// ---- one-shot peer-write exchange over xGMI (last paragraph) ---------------------
+//
+// The per-sweep messages of the sharded lasso are m floats (40 KB at config 2): latency-bound.
+// A ring all-reduce pays 2(G-1) dependent hops; the 8 GPUs of a node are fully connected, so
+// every rank can instead WRITE its contribution straight into a slot of every peer's window
+// (one hop), and every rank sums the G slots it received in rank order - the same bits on every
+// rank.  The window is device memory shared through HIP IPC handles; an entry is an 8-byte
+// {tag, value} granule written by ONE store, so the data is its own flag (no fence between a
+// payload and a flag store, MI355X_MICROARCH.md "Valid forms" R2) and a reader polls until the
+// tag equals the phase it waits for.  All polling is bounded: on a timeout the kernel sets an
+// error word and finishes, the host raises at the next residual check.
+//
+// Kernels that use the window are in kernels_peer.hip; RCCL stays in charge of the large
+// messages (the m x m Gram all-reduce at Init) and of the residual scalars.
+struct PeerView {  // passed to kernels by value
+  static constexpr int kMaxPeers = 8;
+  unsigned long long* win[kMaxPeers];  // win[q]: rank q's window as mapped into THIS process
+  int G = 1, rank = 0;
+  // rehearsal (one process plays one rank of G, every window is its own): a push to "peer q"
+  // lands in source slot q of the local window, so that every slot a poll waits for is filled
+  int rehearse = 0;
+  long long slot = 0;                   // granules per (channel, source rank) slot
+  unsigned* epoch = nullptr;            // device counter, one increment per sweep
+  unsigned* err = nullptr;              // host-mapped: != 0 after a timed-out poll
+};
+
+class PeerExchange {
+ public:
+  static constexpr int kChannels = 2;
+  // Collective over `comm` (handles travel through its AllGather; every step's outcome is
+  // agreed across the ranks, so either all of them get a window or none does).  Returns nullptr
+  // and the reason in *why when the window cannot be set up or its self test fails.
+  static PeerExchange* Create(Comm* comm, int64_t slot_floats, int rehearse_ranks, std::string* why);
+  ~PeerExchange();
+  const PeerView& view() const { return view_; }
+  int64_t slot() const { return view_.slot; }
+  // Collective: push a known pattern through both channels and check what arrives (throws).
+  void SelfTest();
+  // Throws if a kernel reported a timed-out poll since the last call (stream must be drained).
+  void CheckError();
+
+ private:
+  PeerExchange() {}
+  PeerView view_;
+  void* local_ = nullptr;
+  size_t bytes_ = 0;
+  std::vector<void*> opened_;
+  unsigned* err_host_ = nullptr;
+};
 
 // Which block keys are sharded in the solve being set up / run on this process.
 class ShardSpec {

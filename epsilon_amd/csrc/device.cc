@@ -183,7 +183,7 @@ bool Runtime::ProfWanted(const char* name) const {
 ProfScope::ProfScope(const char* name, int64_t a, int64_t b) {
   Runtime& rt = Runtime::Get();
   on = false;
-  if (!rt.profiling()) return;
+  if (!rt.profiling() || rt.capturing()) return;
   std::string tag = name;
   if (a >= 0) tag += ":" + std::to_string(a);
   if (b >= 0) tag += "x" + std::to_string(b);

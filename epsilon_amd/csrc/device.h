@@ -29,7 +29,8 @@ struct Buffer {
   ~Buffer();
 };
 
-class Comm;  // collective backend (comm.h)
+class Comm;          // collective backend (comm.h)
+class PeerExchange;  // one-shot peer-write window (comm.h)
 
 class Runtime {
  public:
@@ -77,6 +78,11 @@ class Runtime {
 
   Comm* comm() { return comm_; }
   void set_comm(Comm* c) { comm_ = c; }
+  PeerExchange* peer() { return peer_; }
+  void set_peer(PeerExchange* p) { peer_ = p; }
+  // true while the stream is being captured into a hipGraph (no events, no synchronisation)
+  bool capturing() const { return capturing_; }
+  void set_capturing(bool on) { capturing_ = on; }
 
   static constexpr int kMaxSlots = 4096;
 
@@ -93,6 +99,8 @@ class Runtime {
   double* slots_host_ = nullptr;
   int slots_used_ = 0;
   Comm* comm_ = nullptr;
+  PeerExchange* peer_ = nullptr;
+  bool capturing_ = false;
   bool profiling_ = false;
   std::string prof_filter_;
   struct ProfPending { std::string tag; hipEvent_t a, b; };

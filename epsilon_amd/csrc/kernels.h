@@ -6,6 +6,7 @@
 #include "device.h"
 
 namespace eps {
+struct PeerView;
 namespace k {
 
 // ---- K7: BlockVector += -= *=, scalar / diagonal Apply -------------------------------------
@@ -37,8 +38,11 @@ void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, i
 
 // y = alpha * S x + beta * y for a symmetric S in full storage (n x n, leading dimension lds):
 // reads only the lower-triangle tiles, half the bytes of Gemv.
+// `work` (optional, SymvWorkspace(n) elements of S's dtype): per-tile partials at a fixed
+// address instead of a pool allocation per call (launches captured in a hipGraph need that).
 void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, double beta,
-          const DVec& y);
+          const DVec& y, const DVec* work = nullptr);
+int64_t SymvWorkspace(int64_t n);
 
 // y[r] = alpha * sum_{k < nparts} partial[k*rows + r] + beta*y[r], fixed summation order.
 // `add` (optional) is added to the result afterwards: y = (alpha*sum + beta*y) + add.
@@ -55,10 +59,22 @@ struct LassoFusedArgs {
   double lam = 0, sz_alpha = 1, sz_beta = 1, sz_M = 0;
   DVec u, x0, x1, y0, y1, y1prev;   // n each, updated in place
   DVec tpart;                       // LassoFusedGrid(n) * m: per-workgroup partials of A v0'
+  unsigned* epoch = nullptr;        // optional device counter, incremented once per launch
 };
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda);
 int LassoFusedGrid(int64_t n);
 void LassoFusedPass(const LassoFusedArgs& args);
+
+// ---- one-shot peer-write exchange (kernels_peer.hip; PeerView in comm.h) ----------------------
+void PeerBumpEpoch(const PeerView& pv);
+// y = (sum over ranks, in rank order, of alpha * sum_k partial[k*rows + r]) + add
+void PeerReduceExchange(const PeerView& pv, int64_t rows, int nparts, const DVec& partial,
+                        double alpha, const DVec* add, const DVec& y);
+bool PeerSlabApplySupported(const PeerView& pv, int64_t m, int64_t slab, const DVec& D, int64_t ldd);
+// wpad[q*slab + j] = scale * D[:, q*slab + j] . p for every rank q (this rank computes q = rank,
+// lo = rank*slab, pushes it to the peers and gathers theirs); columns >= m give 0.
+void PeerSlabApplyExchange(const PeerView& pv, int64_t m, int64_t slab, int64_t lo, const DVec& D,
+                           int64_t ldd, double scale, const DVec& p, const DVec& wpad);
 
 // ---- K4: dense mat-mat (reference linear/linear_map_multiply.cc:14-37 dgemm_) -------------
 // C (M x N, ldc) = alpha * op(A) (M x K) * op(B) (K x N) + beta * C ; column-major.

@@ -84,8 +84,9 @@ template <int NR>
 __global__ __launch_bounds__(kBlock, 2) void LassoFusedKernel(
     int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
     FusedScalars c, float* u, float* x0, float* x1, float* y0, float* y1, float* y1prev,
-    float* __restrict__ tpart) {
+    float* __restrict__ tpart, unsigned* epoch) {
   __shared__ float red[2][kBlock / 64][2];
+  if (epoch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *epoch += 1u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4 wv[NR], tp[NR];
   int64_t row[NR];
@@ -186,8 +187,11 @@ template <int NR>
 __global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
     int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
     FusedScalars c, float* u, float* x0, float* x1, float* y0, float* y1, float* y1prev,
-    float* __restrict__ tpart) {
+    float* __restrict__ tpart, unsigned* epoch) {
   __shared__ float red[2][kBlock / 64];
+  // sweep counter of the peer exchange (kernels_peer.hip): the two exchange kernels that follow
+  // this pass in stream order tag their granules with it
+  if (epoch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *epoch += 1u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float4 wv[NR], tp[NR];
   int64_t row[NR];
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
 template <int NR>
 void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, const float* w,
                  const FusedScalars& c, float* u, float* x0, float* x1, float* y0, float* y1,
-                 float* y1prev, float* tpart) {
+                 float* y1prev, float* tpart, unsigned* epoch) {
   // default: the streaming kernel (6.0 vs 5.75 TB/s on the 1e4 x 5e4 matrix); "pair" selects the
   // two-column form
   static const char* env = std::getenv("EPSILON_HIP_FUSED_KERNEL");
@@ -288,11 +292,11 @@ void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, co
   if (stream) {
     hipLaunchKernelGGL(LassoFusedStreamKernel<NR>, dim3(grid), dim3(kBlock), 0,
                        Runtime::Get().stream(), m, n, A, lda, w, c, u, x0, x1, y0, y1, y1prev,
-                       tpart);
+                       tpart, epoch);
     return;
   }
   hipLaunchKernelGGL(LassoFusedKernel<NR>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), m,
-                     n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart);
+                     n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart, epoch);
 }
 
 }  // namespace
@@ -308,6 +312,12 @@ int LassoFusedGrid(int64_t n) {
   static const char* env = std::getenv("EPSILON_HIP_FUSED_GRID");  // tuning knob
   if (env && std::atoi(env) > 0) g = std::atoi(env);
   if (g > npairs) g = npairs;
+  if (g < 1) g = 1;
+  // equal shares: with `per` column pairs per workgroup, ceil(npairs / per) workgroups leave no
+  // workgroup a pair short (a 6272-column slab on 512 workgroups is 6 or 7 pairs each - the
+  // launch then lasts as long as the 7s; on 448 workgroups every one has 7)
+  const int64_t per = (npairs + g - 1) / g;
+  g = (npairs + per - 1) / per;
   return static_cast<int>(g < 1 ? 1 : g);
 }
 
@@ -334,7 +344,7 @@ void LassoFusedPass(const LassoFusedArgs& a) {
 #define EPS_FUSED_CASE(NRV)                                                                      \
   LaunchFused<NRV>(grid, a.m, a.n, a.A.as<float>(), a.lda, a.w.as<float>(), c, a.u.as<float>(), \
                    a.x0.as<float>(), a.x1.as<float>(), a.y0.as<float>(), a.y1.as<float>(),      \
-                   a.y1prev.as<float>(), a.tpart.as<float>())
+                   a.y1prev.as<float>(), a.tpart.as<float>(), a.epoch)
   if (need <= 1) EPS_FUSED_CASE(1);
   else if (need <= 2) EPS_FUSED_CASE(2);
   else if (need <= 4) EPS_FUSED_CASE(4);

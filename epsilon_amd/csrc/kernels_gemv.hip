@@ -528,13 +528,18 @@ __global__ __launch_bounds__(kBlock) void SymvReduceKernel(int64_t n, int64_t nb
 }
 
 template <class T>
-void LaunchSymv(int64_t n, double alpha, const T* S, int64_t lds, const T* x, double beta, T* y) {
+void LaunchSymv(int64_t n, double alpha, const T* S, int64_t lds, const T* x, double beta, T* y,
+                void* work) {
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   const int64_t nb = (n + kSB - 1) / kSB;
   const int64_t ntiles = nb * (nb + 1) / 2;
-  auto buf = rt.Alloc(static_cast<size_t>(2 * ntiles * kSB) * sizeof(T));
-  T* prow = static_cast<T*>(buf->p);
+  std::shared_ptr<Buffer> buf;
+  if (work == nullptr) {
+    buf = rt.Alloc(static_cast<size_t>(2 * ntiles * kSB) * sizeof(T));
+    work = buf->p;
+  }
+  T* prow = static_cast<T*>(work);
   T* pcol = prow + ntiles * kSB;
   hipLaunchKernelGGL((SymvTileKernel<T>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, s,
                      n, S, lds, x, prow, pcol);
@@ -545,15 +550,22 @@ void LaunchSymv(int64_t n, double alpha, const T* S, int64_t lds, const T* x, do
 
 }  // namespace
 
+int64_t SymvWorkspace(int64_t n) {
+  const int64_t nb = (n + kSB - 1) / kSB;
+  return 2 * (nb * (nb + 1) / 2) * kSB;
+}
+
 void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, double beta,
-          const DVec& y) {
+          const DVec& y, const DVec* work) {
   EPS_CHECK(S.dt == x.dt && S.dt == y.dt && x.n == n && y.n == n && lds >= n);
   EPS_CHECK_MSG(n == 0 || S.n >= (n - 1) * lds + n, "symv: matrix buffer too small");
   EPS_CHECK_MSG(x.data() != y.data(), "symv: x and y alias");
   if (n == 0) return;
+  if (work) EPS_CHECK(work->dt == S.dt && work->n >= SymvWorkspace(n));
   ProfScope prof("symv", n);
-  if (S.dt == F32) LaunchSymv<float>(n, alpha, S.as<float>(), lds, x.as<float>(), beta, y.as<float>());
-  else LaunchSymv<double>(n, alpha, S.as<double>(), lds, x.as<double>(), beta, y.as<double>());
+  void* wp = work ? work->data() : nullptr;
+  if (S.dt == F32) LaunchSymv<float>(n, alpha, S.as<float>(), lds, x.as<float>(), beta, y.as<float>(), wp);
+  else LaunchSymv<double>(n, alpha, S.as<double>(), lds, x.as<double>(), beta, y.as<double>(), wp);
   EPS_HIP(hipGetLastError());
 }
 

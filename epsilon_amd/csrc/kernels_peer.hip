@@ -1,0 +1,367 @@
+// One-shot peer-write exchange kernels for the column-sharded fused lasso sweep (SURVEY.md 8(e),
+// mode E1; the loop being sharded is reference algorithms/prox_admm.cc:141-147).
+//
+// A sharded sweep has two places where every rank needs something from every other rank:
+//   (1) the forward product A v' is a sum over the ranks' column slabs  (m floats, all-reduce);
+//   (2) the cached inverse is applied by row slabs                       (m/G floats each, all-gather).
+// Both messages are tens of KB, so they are latency-bound; a ring collective pays 2(G-1) hops and
+// a kernel launch of its own.  Here each exchange rides INSIDE the kernel that produces the data:
+//
+//   PeerReduceExchangeKernel      sums this rank's per-workgroup partials of A v' (fixed order),
+//                                 WRITES the m results into slot[rank] of every peer's window
+//                                 (one hop over the direct xGMI links), then polls its own window
+//                                 until all G slots carry this phase's tag and adds them in rank
+//                                 order (identical bits on every rank), + the constant rhs.
+//   PeerSlabApplyExchangeKernel   w_slab = scale * Dinv[:, slab]^T p (the cached inverse is
+//                                 symmetric, so a row slab is read as contiguous columns), pushes
+//                                 the slab to every peer and gathers the other slabs into w.
+//
+// An entry of a window is an 8-byte {tag, value} granule written by ONE system-scope store, so
+// the data is its own flag: no fence between payload and flag, no ordering assumption on the
+// fabric (MI355X_MICROARCH.md, Valid forms, R2).  tag = 2*epoch + phase, epoch = a device counter
+// the fused pass increments once per sweep - kernel arguments are frozen when the sweep is
+// replayed from a hipGraph, the counter is not.  A slot is written again only after two further
+// exchanges have completed, each of which the writer could only pass once the reader had finished
+// the kernel that read the slot (stream order), so one buffer per channel suffices.
+//
+// Every poll is bounded (kTimeoutTicks of the 100 MHz constant clock): a missing peer ends in an
+// error word, never in a hung grid.  Waiting happens only in these two small kernels, never in the
+// chip-filling streaming pass, so ranks that share one GPU (tests) cannot starve each other.
+#include <hip/hip_runtime.h>
+
+#include "comm.h"
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr unsigned long long kTimeoutTicks = 200000000ull;  // 2 s at 100 MHz
+
+typedef unsigned long long u64;
+
+__device__ inline u64 Granule(unsigned tag, float v) {
+  return (static_cast<u64>(tag) << 32) | static_cast<u64>(__float_as_uint(v));
+}
+
+__device__ inline void PushGranule(u64* dst, u64 g) {
+  __hip_atomic_store(dst, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ inline u64 LoadGranule(const u64* src) {
+  return __hip_atomic_load(const_cast<u64*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// After the first timed-out poll every later poll gives up at once (a device-side copy of the
+// error word sits 64 bytes behind the epoch counter), so a missing peer costs one timeout, not
+// one per kernel until the host looks.
+__device__ inline unsigned* DevErr(const PeerView& pv) { return pv.epoch + 16; }
+
+__device__ inline bool Failed(const PeerView& pv) {
+  return __hip_atomic_load(DevErr(pv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+
+__device__ inline void ReportTimeout(const PeerView& pv, unsigned code) {
+  __hip_atomic_store(DevErr(pv), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(pv.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// address of granule i of (channel, source) in the window of rank `dest`
+__device__ inline u64* Slot(const PeerView& pv, int dest, int channel, int source, long long i) {
+  return pv.win[dest] + (static_cast<long long>(channel) * pv.G + source) * pv.slot + i;
+}
+
+// Push one value into (channel, i) of every rank's window, this rank's own included.
+__device__ inline void PushAll(const PeerView& pv, int channel, long long i, unsigned tag, float v) {
+  const u64 g = Granule(tag, v);
+#pragma unroll
+  for (int q = 0; q < PeerView::kMaxPeers; ++q) {
+    if (q < pv.G) PushGranule(Slot(pv, q, channel, pv.rehearse ? q : pv.rank, i), g);
+  }
+}
+
+// Wait for the E consecutive granules i .. i+E-1 of (channel, source q) for every q < G; returns
+// the values.  All E*G loads of a round are issued together; lanes whose granules have all arrived
+// leave the loop.
+template <int E>
+__device__ inline bool PollAll(const PeerView& pv, int channel, long long i, unsigned tag,
+                               float (&val)[E][PeerView::kMaxPeers], unsigned code) {
+  const u64 t0 = wall_clock64();
+  for (;;) {
+    u64 x[E][PeerView::kMaxPeers];
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+      for (int q = 0; q < PeerView::kMaxPeers; ++q)
+        x[e][q] = q < pv.G ? LoadGranule(Slot(pv, pv.rank, channel, q, i + e)) : 0;
+    bool ok = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+      for (int q = 0; q < PeerView::kMaxPeers; ++q) {
+        if (q < pv.G) {
+          ok = ok && static_cast<unsigned>(x[e][q] >> 32) == tag;
+          val[e][q] = __uint_as_float(static_cast<unsigned>(x[e][q]));
+        }
+      }
+    if (ok) return true;
+    if (Failed(pv) || wall_clock64() - t0 > kTimeoutTicks) {
+      ReportTimeout(pv, code);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int q = 0; q < PeerView::kMaxPeers; ++q) val[e][q] = 0.0f;
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+__device__ inline bool PollOne(const PeerView& pv, int channel, int source, long long i,
+                               unsigned tag, float* val, unsigned code) {
+  const u64 t0 = wall_clock64();
+  const u64* g = Slot(pv, pv.rank, channel, source, i);
+  for (;;) {
+    const u64 x = LoadGranule(g);
+    if (static_cast<unsigned>(x >> 32) == tag) {
+      *val = __uint_as_float(static_cast<unsigned>(x));
+      return true;
+    }
+    if (Failed(pv) || wall_clock64() - t0 > kTimeoutTicks) {
+      ReportTimeout(pv, code);
+      *val = 0.0f;
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+__global__ void PeerBumpEpochKernel(PeerView pv) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *pv.epoch += 1u;
+}
+
+// y[r] = (sum_q  alpha * sum_k partial_q[k*rows + r])  + add[r],   q over ranks in order.
+// A workgroup owns 32 rows: thread (rq, pl) = (t & 7, t >> 3) reads the float4 of rows 4 rq .. 4 rq + 3
+// of the partial vectors k = pl, pl + 32, ... (16-byte loads, all of a thread's loads independent:
+// 512 partials = 16 loads in flight per thread, 313 workgroups at m = 1e4 - the 20 MB of partials
+// of an 8-way sharded sweep have to come in at chip rate, the exchange behind them is the
+// latency that matters).  Summation order is fixed: k ascending per thread, then the 32 part
+// lanes by three shuffle steps inside a wave and the 4 waves in order.
+constexpr int kRQ = 8;                 // row quads per workgroup (32 rows)
+constexpr int kPL = kBlock / kRQ;      // 32 part lanes
+
+__global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
+    PeerView pv, long long rows, int nparts, const float* __restrict__ partial, float alpha,
+    const float* __restrict__ add, float* __restrict__ y) {
+  __shared__ float4 part[kBlock / 64][kRQ];
+  const int t = threadIdx.x, rq = t & (kRQ - 1), pl = t >> 3, wave = t >> 6;
+  const long long r0 = (static_cast<long long>(blockIdx.x) * kRQ + rq) * 4;  // rows % 4 == 0
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r0 < rows) {
+    const float* p = partial + r0;
+    int k = pl;
+    for (; k + 7 * kPL < nparts; k += 8 * kPL) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float4*>(p + static_cast<long long>(k + u * kPL) * rows);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s.x += v[u].x;
+        s.y += v[u].y;
+        s.z += v[u].z;
+        s.w += v[u].w;
+      }
+    }
+    for (; k < nparts; k += kPL) {
+      const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(k) * rows);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  }
+  // the 8 part lanes of a wave sit 8 lanes apart
+#pragma unroll
+  for (int off = 32; off >= 8; off >>= 1) {
+    s.x += __shfl_down(s.x, off, 64);
+    s.y += __shfl_down(s.y, off, 64);
+    s.z += __shfl_down(s.z, off, 64);
+    s.w += __shfl_down(s.w, off, 64);
+  }
+  if ((t & 63) < kRQ) part[wave][rq] = s;
+  __syncthreads();
+  if (t >= kRQ || r0 >= rows) return;
+  const unsigned tag = 2u * (*pv.epoch) + 1u;
+  const float4 a = part[0][rq], b = part[1][rq], c = part[2][rq], d = part[3][rq];
+  const float mine[4] = {alpha * (((a.x + b.x) + c.x) + d.x), alpha * (((a.y + b.y) + c.y) + d.y),
+                         alpha * (((a.z + b.z) + c.z) + d.z), alpha * (((a.w + b.w) + c.w) + d.w)};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) PushAll(pv, 0, r0 + e, tag, mine[e]);
+  float out[4];
+  float val[4][PeerView::kMaxPeers];
+  PollAll<4>(pv, 0, r0, tag, val, 1u);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float acc = val[e][0];
+#pragma unroll
+    for (int q = 1; q < PeerView::kMaxPeers; ++q)
+      if (q < pv.G) acc += val[e][q];
+    if (add) acc += add[r0 + e];
+    out[e] = acc;
+  }
+  *reinterpret_cast<float4*>(y + r0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// w[q*slab + j] for all q: this rank computes j < slab of its own slab
+//   w_own[j] = scale * D[:, lo + j] . p      (0 for lo + j >= m, the padding of the last slab)
+// CP columns per workgroup pass, the CP dot products reduced by wave shuffles and across the 4
+// waves in a fixed order (GemvT2Kernel's scheme); the lanes that hold the results push them.  Afterwards every thread gathers a share of the G*slab granules of
+// w from the local window into the plain vector the streaming pass reads.
+template <int CP>
+__global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
+    PeerView pv, long long m, long long slab, long long lo, const float* __restrict__ D,
+    long long ldd, float scale, const float* __restrict__ p, float* __restrict__ wpad) {
+  // (p is read straight from global memory: a thread only ever needs the entries of its own row
+  // chunks, nothing is shared between threads, and a workgroup takes one or two passes - staging
+  // the m floats in LDS first cost a third of the kernel's traffic)
+  __shared__ float red[kBlock / 64][CP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned tag = 2u * (*pv.epoch) + 2u;
+  const long long npass = (slab + CP - 1) / CP;
+  const long long nvec = m / 4;
+  for (long long pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    const long long j0 = pass * CP;
+    float acc[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = 0.0f;
+    // RU row chunks x CP columns = 8 independent 16-byte loads per thread and step
+    constexpr int RU = 8 / CP;
+    bool live[CP];
+    const float* colp[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const long long col = lo + j0 + c;
+      live[c] = j0 + c < slab && col < m;
+      colp[c] = D + (live[c] ? col : 0) * ldd;
+    }
+    for (long long q0 = threadIdx.x; q0 < nvec; q0 += kBlock * RU) {
+      float4 a[RU][CP], xv[RU];
+#pragma unroll
+      for (int r = 0; r < RU; ++r) {
+        const long long q = q0 + static_cast<long long>(r) * kBlock;
+        const bool in = q < nvec;
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+          a[r][c] = (in && live[c]) ? *reinterpret_cast<const float4*>(colp[c] + q * 4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[r] = in ? reinterpret_cast<const float4*>(p)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < RU; ++r) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) {
+          acc[c] += a[r][c].x * xv[r].x;
+          acc[c] += a[r][c].y * xv[r].y;
+          acc[c] += a[r][c].z * xv[r].z;
+          acc[c] += a[r][c].w * xv[r].w;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      float v = acc[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < CP && j0 + threadIdx.x < slab) {
+      const int c = threadIdx.x;
+      const float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+      PushAll(pv, 1, j0 + c, tag, scale * t);
+      // the own slab goes straight into w: no workgroup of this grid ever waits for another
+      // workgroup of the same grid, only for other GPUs
+      if (!pv.rehearse) wpad[static_cast<long long>(pv.rank) * slab + j0 + c] = scale * t;
+    }
+    __syncthreads();
+  }
+  // gather the other ranks' slabs: granule g = q*slab + j of channel 1
+  const long long total = static_cast<long long>(pv.G) * slab;
+  for (long long g = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; g < total;
+       g += static_cast<long long>(gridDim.x) * kBlock) {
+    const int q = static_cast<int>(g / slab);
+    if (q == pv.rank && !pv.rehearse) continue;
+    const long long j = g - q * slab;
+    float v;
+    PollOne(pv, 1, q, j, tag, &v, 2u);
+    wpad[g] = v;
+  }
+}
+
+}  // namespace
+
+void PeerBumpEpoch(const PeerView& pv) {
+  hipLaunchKernelGGL(PeerBumpEpochKernel, dim3(1), dim3(64), 0, Runtime::Get().stream(), pv);
+  EPS_HIP(hipGetLastError());
+}
+
+void PeerReduceExchange(const PeerView& pv, int64_t rows, int nparts, const DVec& partial,
+                        double alpha, const DVec* add, const DVec& y) {
+  EPS_CHECK(partial.dt == F32 && y.dt == F32 && y.n == rows);
+  EPS_CHECK(partial.n >= static_cast<int64_t>(nparts) * rows && nparts >= 1);
+  EPS_CHECK_MSG(rows <= pv.slot, "peer exchange: " << rows << " rows exceed the window slot of "
+                                                   << pv.slot);
+  if (add) EPS_CHECK(add->n == rows && add->dt == F32);
+  if (rows == 0) return;
+  ProfScope prof("peer_reduce_exchange", rows, nparts);
+  EPS_CHECK_MSG(rows % 4 == 0 && reinterpret_cast<uintptr_t>(partial.data()) % 16 == 0 &&
+                    reinterpret_cast<uintptr_t>(y.data()) % 16 == 0,
+                "peer exchange: rows must be a multiple of 4 and the buffers 16-byte aligned");
+  const unsigned grid = static_cast<unsigned>((rows / 4 + kRQ - 1) / kRQ);
+  hipLaunchKernelGGL(PeerReduceExchangeKernel, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(),
+                     pv, static_cast<long long>(rows), nparts, partial.as<float>(),
+                     static_cast<float>(alpha), add ? add->as<float>() : nullptr, y.as<float>());
+  EPS_HIP(hipGetLastError());
+}
+
+bool PeerSlabApplySupported(const PeerView& pv, int64_t m, int64_t slab, const DVec& D, int64_t ldd) {
+  return D.dt == F32 && m % 4 == 0 && ldd % 4 == 0 && slab <= pv.slot &&
+         reinterpret_cast<uintptr_t>(D.data()) % 16 == 0;
+}
+
+void PeerSlabApplyExchange(const PeerView& pv, int64_t m, int64_t slab, int64_t lo, const DVec& D,
+                           int64_t ldd, double scale, const DVec& p, const DVec& wpad) {
+  EPS_CHECK(PeerSlabApplySupported(pv, m, slab, D, ldd));
+  EPS_CHECK(p.n == m && p.dt == F32 && wpad.dt == F32 && wpad.n >= slab * pv.G);
+  EPS_CHECK(D.n >= (m - 1) * ldd + m && lo >= 0);
+  EPS_CHECK(reinterpret_cast<uintptr_t>(p.data()) % 16 == 0);
+  ProfScope prof("peer_slab_apply_exchange", m, slab);
+  const size_t lds = 0;
+  hipStream_t s = Runtime::Get().stream();
+  // enough workgroups to fill the chip twice over: 4 columns per pass while that gives >= 512
+  // passes, 2 below (at m = 1e4 and 8 ranks: 626 passes of 2 columns)
+  const bool wide = slab / 4 >= 512;
+  const int64_t cp = wide ? 4 : 2;
+  int64_t grid = (slab + cp - 1) / cp;
+  // at most four workgroups (16 waves of the 32) per CU: the polling tail must never fill the
+  // chip (ranks that share one GPU in the tests need room to run beside each other)
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  if (wide)
+    hipLaunchKernelGGL(PeerSlabApplyExchangeKernel<4>, dim3(static_cast<unsigned>(grid)), dim3(kBlock),
+                       lds, s, pv, static_cast<long long>(m), static_cast<long long>(slab),
+                       static_cast<long long>(lo), D.as<float>(), static_cast<long long>(ldd),
+                       static_cast<float>(scale), p.as<float>(), wpad.as<float>());
+  else
+    hipLaunchKernelGGL(PeerSlabApplyExchangeKernel<2>, dim3(static_cast<unsigned>(grid)), dim3(kBlock),
+                       lds, s, pv, static_cast<long long>(m), static_cast<long long>(slab),
+                       static_cast<long long>(lo), D.as<float>(), static_cast<long long>(ldd),
+                       static_cast<float>(scale), p.as<float>(), wpad.as<float>());
+  EPS_HIP(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace eps

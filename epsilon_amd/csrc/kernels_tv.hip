@@ -18,14 +18,29 @@
 // d_i = cost(u_i=1) - cost(u_i=0) is  d_i = a_i + clip(d_{i-1}, -lam, lam)  - a composition of
 // clamp-shift maps (p, lo, hi), which is associative => a parallel SCAN; the backward decode
 // u_i = [d_i < -lam] or [d_i < lam and u_{i+1}] is a "first definite value to the right" scan.
-// Region means come from one fp64 prefix sum of y, so a level costs a few streaming passes and
-// the number of levels is ~log2(#constant pieces of the solution).
-//
 // All decisions are taken in fp64 (data may be f32), so the partition matches the fp64 DP except
 // at exact ties.
+//
+// Data layout (round 2: 17 bytes per sample and level instead of ~70).  The whole state of the
+// recursion is ONE byte per sample,
+//     bit 0 head of a region | bit 1 end | bits 2-3 side of the left neighbour (at heads)
+//     bits 4-5 side of the right neighbour (at ends) | bits 6-7 class (0 / 1 / 2 = copy, 3 = done)
+// plus a sparse table indexed by region head (tau, finished flag) that only region heads touch,
+// plus the fp64 prefix sums of y that only region boundaries touch.  A level is three scans over
+// the byte (and, for the first, over y):
+//     forward   clamp-shift scan: reads y + state, writes the class into the state byte; the
+//               region head of a sample (to find its tau) is the running maximum of head
+//               positions - inside a tile a workgroup scan, across tiles a pre-scanned table;
+//               samples of regions that finished one level earlier get x = tau here, once;
+//     backward  decode scan: state -> state (u replaces the class);
+//     backward  boundary scan (nearest new end / nearest old end): finds the cuts, writes the
+//               next level's state byte into the second buffer and, at every new head, the
+//               region record (tau from the prefix sums, "did not split" = finished).
+// Each scan is reduce -> scan of the tile aggregates -> apply; tiles are read with 16-byte loads.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -35,218 +50,20 @@ namespace k {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kItems = 8;
-constexpr int kTile = kBlock * kItems;
+constexpr int kAggItems = 8;
+constexpr int kAggTile = kBlock * kAggItems;
+constexpr int kFwdItems = 8;               // samples per thread in the scans that read y
+constexpr int kFwdTile = kBlock * kFwdItems;
+constexpr int kByteItems = 16;             // samples per thread in the byte scans
+constexpr int32_t kInf = 0x7fffffff;
 
-// ---- generic 3-phase scan --------------------------------------------------------------------
-// Op: struct with  using S;  __device__ S load(int64 i);  static S combine(S acc, S next);
-//     static S identity();  __device__ void store(int64 i, S inclusive);
-// REV scans from the last element to the first.
-
-template <class S, class Op> __device__ inline S BlockExclusive(S mine, S* lds, S* total) {
-  // inclusive Hillis-Steele over the 256 thread aggregates, in scan order = thread order
-  const int t = threadIdx.x;
-  lds[t] = mine;
-  __syncthreads();
-  for (int off = 1; off < kBlock; off <<= 1) {
-    S v = lds[t];
-    if (t >= off) v = Op::combine(lds[t - off], v);
-    __syncthreads();
-    lds[t] = v;
-    __syncthreads();
-  }
-  S excl = t == 0 ? Op::identity() : lds[t - 1];
-  *total = lds[kBlock - 1];
-  __syncthreads();
-  return excl;
-}
-
-template <class Op, bool REV>
-__global__ __launch_bounds__(kBlock) void ScanReduceKernel(Op op, int64_t n,
-                                                           typename Op::S* agg) {
-  using S = typename Op::S;
-  __shared__ S lds[kBlock];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + static_cast<int64_t>(threadIdx.x) * kItems;
-  S acc = Op::identity();
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t pos = base + k;  // position in scan order
-    if (pos < n) acc = Op::combine(acc, op.load(REV ? n - 1 - pos : pos));
-  }
-  S total;
-  BlockExclusive<S, Op>(acc, lds, &total);
-  if (threadIdx.x == 0) agg[blockIdx.x] = total;
-}
-
-// exclusive scan of the block aggregates, in place, by one workgroup: every thread owns a
-// contiguous chunk (sequential reduce, ONE workgroup scan of the 256 chunk totals, sequential
-// write-back), so the number of barriers does not grow with the number of blocks
-template <class Op>
-__global__ __launch_bounds__(kBlock) void ScanAggKernel(int64_t nb, typename Op::S* agg) {
-  using S = typename Op::S;
-  __shared__ S lds[kBlock];
-  const int64_t chunk = (nb + kBlock - 1) / kBlock;
-  const int64_t b0 = static_cast<int64_t>(threadIdx.x) * chunk;
-  int64_t b1 = b0 + chunk;
-  if (b1 > nb) b1 = nb;
-  S acc = Op::identity();
-  for (int64_t i = b0; i < b1; ++i) acc = Op::combine(acc, agg[i]);
-  S total;
-  S run = BlockExclusive<S, Op>(acc, lds, &total);
-  for (int64_t i = b0; i < b1; ++i) {
-    const S v = agg[i];
-    agg[i] = run;
-    run = Op::combine(run, v);
-  }
-}
-
-// Two-level form of the same step for many blocks (n = 1e8: 48 828 aggregates, which the single
-// workgroup above walks in 256 serial chains of 191 dependent loads, ~200 us per scan and 6 ms of
-// a 50 ms prox): a tile of aggregates per workgroup, the tile totals scanned by ScanAggKernel.
-template <class Op>
-__global__ __launch_bounds__(kBlock) void AggReduceKernel(int64_t nb, const typename Op::S* agg,
-                                                          typename Op::S* agg2) {
-  using S = typename Op::S;
-  __shared__ S lds[kBlock];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + static_cast<int64_t>(threadIdx.x) * kItems;
-  S acc = Op::identity();
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t pos = base + k;
-    if (pos < nb) acc = Op::combine(acc, agg[pos]);
-  }
-  S total;
-  BlockExclusive<S, Op>(acc, lds, &total);
-  if (threadIdx.x == 0) agg2[blockIdx.x] = total;
-}
-
-template <class Op>
-__global__ __launch_bounds__(kBlock) void AggApplyKernel(int64_t nb, typename Op::S* agg,
-                                                         const typename Op::S* agg2) {
-  using S = typename Op::S;
-  __shared__ S lds[kBlock];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + static_cast<int64_t>(threadIdx.x) * kItems;
-  S item[kItems];
-  S acc = Op::identity();
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t pos = base + k;
-    item[k] = pos < nb ? agg[pos] : Op::identity();
-    acc = Op::combine(acc, item[k]);
-  }
-  S total;
-  S excl = BlockExclusive<S, Op>(acc, lds, &total);
-  S run = Op::combine(agg2[blockIdx.x], excl);
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t pos = base + k;
-    if (pos < nb) {
-      agg[pos] = run;  // exclusive prefix of block `pos`
-      run = Op::combine(run, item[k]);
-    }
-  }
-}
-
-template <class Op, bool REV>
-__global__ __launch_bounds__(kBlock) void ScanApplyKernel(Op op, int64_t n,
-                                                          const typename Op::S* agg) {
-  using S = typename Op::S;
-  __shared__ S lds[kBlock];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kTile + static_cast<int64_t>(threadIdx.x) * kItems;
-  S item[kItems];
-  S acc = Op::identity();
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t pos = base + k;
-    item[k] = pos < n ? op.load(REV ? n - 1 - pos : pos) : Op::identity();
-    acc = Op::combine(acc, item[k]);
-  }
-  S total;
-  S excl = BlockExclusive<S, Op>(acc, lds, &total);
-  S run = Op::combine(agg[blockIdx.x], excl);
-#pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t pos = base + k;
-    if (pos < n) {
-      run = Op::combine(run, item[k]);
-      op.store(REV ? n - 1 - pos : pos, run);
-    }
-  }
-}
-
-template <class Op, bool REV> void RunScan(const Op& op, int64_t n) {
-  if (n <= 0) return;
-  Runtime& rt = Runtime::Get();
-  hipStream_t s = rt.stream();
-  const int64_t nb = (n + kTile - 1) / kTile;
-  auto aggbuf = rt.Alloc(static_cast<size_t>(nb) * sizeof(typename Op::S));
-  auto* agg = static_cast<typename Op::S*>(aggbuf->p);
-  hipLaunchKernelGGL((ScanReduceKernel<Op, REV>), dim3(nb), dim3(kBlock), 0, s, op, n, agg);
-  if (nb > 2 * kTile) {
-    const int64_t nb2 = (nb + kTile - 1) / kTile;
-    auto agg2buf = rt.Alloc(static_cast<size_t>(nb2) * sizeof(typename Op::S));
-    auto* agg2 = static_cast<typename Op::S*>(agg2buf->p);
-    hipLaunchKernelGGL((AggReduceKernel<Op>), dim3(nb2), dim3(kBlock), 0, s, nb, agg, agg2);
-    hipLaunchKernelGGL((ScanAggKernel<Op>), dim3(1), dim3(kBlock), 0, s, nb2, agg2);
-    hipLaunchKernelGGL((AggApplyKernel<Op>), dim3(nb2), dim3(kBlock), 0, s, nb, agg, agg2);
-  } else {
-    hipLaunchKernelGGL((ScanAggKernel<Op>), dim3(1), dim3(kBlock), 0, s, nb, agg);
-  }
-  hipLaunchKernelGGL((ScanApplyKernel<Op, REV>), dim3(nb), dim3(kBlock), 0, s, op, n, agg);
-}
-
-// ---- scan operators ---------------------------------------------------------------------------
-
-template <class T> struct PrefixSumOp {  // P[i+1] = sum_{k<=i} y_k  (fp64)
-  using S = double;
-  const T* y;
-  double* P;  // n + 1 entries, P[0] written by the launcher
-  __device__ S load(int64_t i) const { return static_cast<double>(y[i]); }
-  __device__ static S combine(S a, S b) { return a + b; }
-  __device__ static S identity() { return 0.0; }
-  __device__ void store(int64_t i, S v) const { P[i + 1] = v; }
-};
+// ---- scan algebra ---------------------------------------------------------------------------------
 
 struct ClipMap {
   double p, lo, hi;
 };
-
-// State of the divide-and-conquer, one entry per sample.
-template <class T> struct TvState {
-  const T* y;
-  const double* P;
-  int32_t* L;        // region start of sample i
-  int32_t* R;        // region end of sample i
-  int8_t* cl;        // at region starts: +1 neighbour below, -1 above, 0 none
-  int8_t* cr;        // at region ends
-  uint8_t* done;     // region finished (x written)
-  uint8_t* s;        // forward classification: 0 force-0, 1 force-1, 2 copy from the right
-  uint8_t* u;        // binary labelling of this level
-  double lam;
-  int64_t n;
-
-  __device__ double Tau(int32_t l, int32_t r) const {
-    const double tot = P[r + 1] - P[l] - lam * (static_cast<double>(cl[l]) + static_cast<double>(cr[r]));
-    return tot / static_cast<double>(r - l + 1);
-  }
-  __device__ double Cost(int64_t i, int32_t l, int32_t r) const {  // a_i = tau - y'_i
-    double yp = static_cast<double>(y[i]);
-    if (i == l) yp -= lam * static_cast<double>(cl[l]);
-    if (i == r) yp -= lam * static_cast<double>(cr[r]);
-    return Tau(l, r) - yp;
-  }
-};
-
-template <class T> struct ClipScanOp {  // forward: d_i, stores the classification s_i
+struct ClipAlg {
   using S = ClipMap;
-  TvState<T> st;
-  __device__ S load(int64_t i) const {
-    if (st.done[i]) return S{0.0, 0.0, 0.0};  // constant map: finished regions are inert
-    const int32_t l = st.L[i], r = st.R[i];
-    const double a = st.Cost(i, l, r);
-    if (i == l) return S{0.0, a, a};  // region head: d_l = a_l, history cut
-    return S{a, a - st.lam, a + st.lam};
-  }
   __device__ static S combine(S f, S g) {  // g after f
     S o;
     o.p = f.p + g.p;
@@ -255,107 +72,532 @@ template <class T> struct ClipScanOp {  // forward: d_i, stores the classificati
     return o;
   }
   __device__ static S identity() { return S{0.0, -INFINITY, INFINITY}; }
-  __device__ void store(int64_t i, S m) const {
-    if (st.done[i]) return;
-    const double d = fmin(fmax(m.p, m.lo), m.hi);  // the composed map applied to 0
-    uint8_t cls;
-    if (i == st.R[i]) cls = d < 0.0 ? 1 : 0;  // region end: definite
-    else if (d < -st.lam) cls = 1;
-    else if (d >= st.lam) cls = 0;
-    else cls = 2;
-    st.s[i] = cls;
-  }
 };
-
-template <class T> struct DecodeScanOp {  // backward: u_i = first definite class to the right
-  using S = uint8_t;
-  TvState<T> st;
-  __device__ S load(int64_t i) const { return st.done[i] ? uint8_t(0) : st.s[i]; }
+struct DecodeAlg {  // first definite class in scan order wins
+  using S = int;
   __device__ static S combine(S acc, S next) { return next != 2 ? next : acc; }
   __device__ static S identity() { return 2; }
-  __device__ void store(int64_t i, S v) const { st.u[i] = v; }
 };
-
-struct HeadScanOp {  // forward max of head positions -> new L
+struct Int2 {
+  int32_t a, b;
+};
+struct MinAlg {
+  using S = Int2;
+  __device__ static S combine(S x, S y) { return S{x.a < y.a ? x.a : y.a, x.b < y.b ? x.b : y.b}; }
+  __device__ static S identity() { return S{kInf, kInf}; }
+};
+struct MaxAlg {
   using S = int32_t;
-  const uint8_t* head;
-  const uint8_t* done;
-  int32_t* L;
-  __device__ S load(int64_t i) const { return head[i] ? static_cast<int32_t>(i) : -1; }
-  __device__ static S combine(S a, S b) { return a > b ? a : b; }
+  __device__ static S combine(S x, S y) { return x > y ? x : y; }
   __device__ static S identity() { return -1; }
-  __device__ void store(int64_t i, S v) const {
-    if (!done[i]) L[i] = v;
+};
+struct SumAlg {
+  using S = double;
+  __device__ static S combine(S x, S y) { return x + y; }
+  __device__ static S identity() { return 0.0; }
+};
+
+template <class S> __device__ inline S ShflUp(const S& v, int off) {
+  constexpr int W = (sizeof(S) + 3) / 4;
+  int w[W] = {};
+  memcpy(w, &v, sizeof(S));
+#pragma unroll
+  for (int k = 0; k < W; ++k) w[k] = __shfl_up(w[k], off, 64);
+  S o;
+  memcpy(&o, w, sizeof(S));
+  return o;
+}
+
+// Exclusive scan of one value per thread over the workgroup, in thread order: shuffles inside a
+// wave, the 4 wave totals through LDS.  *total = the workgroup aggregate.
+template <class Alg>
+__device__ inline typename Alg::S BlockExclusive(typename Alg::S mine, typename Alg::S* lds,
+                                                 typename Alg::S* total) {
+  using S = typename Alg::S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  S incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const S up = ShflUp(incl, off);
+    if (lane >= off) incl = Alg::combine(up, incl);
+  }
+  if (lane == 63) lds[wave] = incl;
+  __syncthreads();
+  S before = Alg::identity();
+  for (int w = 0; w < wave; ++w) before = Alg::combine(before, lds[w]);
+  S tot = lds[0];
+  for (int w = 1; w < kBlock / 64; ++w) tot = Alg::combine(tot, lds[w]);
+  *total = tot;
+  S excl = ShflUp(incl, 1);
+  if (lane == 0) excl = Alg::identity();
+  excl = Alg::combine(before, excl);
+  __syncthreads();
+  return excl;
+}
+
+// ---- scan of the tile aggregates (exclusive, in place) -------------------------------------------
+
+// one workgroup: every thread owns a contiguous chunk
+template <class Alg>
+__global__ __launch_bounds__(kBlock) void AggScanKernel(int64_t nb, typename Alg::S* agg) {
+  using S = typename Alg::S;
+  __shared__ S lds[kBlock / 64];
+  const int64_t chunk = (nb + kBlock - 1) / kBlock;
+  const int64_t b0 = static_cast<int64_t>(threadIdx.x) * chunk;
+  int64_t b1 = b0 + chunk;
+  if (b1 > nb) b1 = nb;
+  S acc = Alg::identity();
+  for (int64_t i = b0; i < b1; ++i) acc = Alg::combine(acc, agg[i]);
+  S total;
+  S run = BlockExclusive<Alg>(acc, lds, &total);
+  for (int64_t i = b0; i < b1; ++i) {
+    const S v = agg[i];
+    agg[i] = run;
+    run = Alg::combine(run, v);
+  }
+}
+
+// two-level form for many tiles (n = 1e8: tens of thousands of aggregates)
+template <class Alg>
+__global__ __launch_bounds__(kBlock) void AggReduceKernel(int64_t nb, const typename Alg::S* agg,
+                                                          typename Alg::S* agg2) {
+  using S = typename Alg::S;
+  __shared__ S lds[kBlock / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kAggTile + static_cast<int64_t>(threadIdx.x) * kAggItems;
+  S acc = Alg::identity();
+#pragma unroll
+  for (int k = 0; k < kAggItems; ++k)
+    if (base + k < nb) acc = Alg::combine(acc, agg[base + k]);
+  S total;
+  BlockExclusive<Alg>(acc, lds, &total);
+  if (threadIdx.x == 0) agg2[blockIdx.x] = total;
+}
+
+template <class Alg>
+__global__ __launch_bounds__(kBlock) void AggApplyKernel(int64_t nb, typename Alg::S* agg,
+                                                         const typename Alg::S* agg2) {
+  using S = typename Alg::S;
+  __shared__ S lds[kBlock / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kAggTile + static_cast<int64_t>(threadIdx.x) * kAggItems;
+  S item[kAggItems];
+  S acc = Alg::identity();
+#pragma unroll
+  for (int k = 0; k < kAggItems; ++k) {
+    item[k] = base + k < nb ? agg[base + k] : Alg::identity();
+    acc = Alg::combine(acc, item[k]);
+  }
+  S total;
+  S excl = BlockExclusive<Alg>(acc, lds, &total);
+  S run = Alg::combine(agg2[blockIdx.x], excl);
+#pragma unroll
+  for (int k = 0; k < kAggItems; ++k) {
+    if (base + k < nb) {
+      agg[base + k] = run;
+      run = Alg::combine(run, item[k]);
+    }
+  }
+}
+
+template <class Alg> void RunAggScan(int64_t nb, typename Alg::S* agg) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  if (nb > 2 * kAggTile) {
+    const int64_t nb2 = (nb + kAggTile - 1) / kAggTile;
+    auto buf = rt.Alloc(static_cast<size_t>(nb2) * sizeof(typename Alg::S));
+    auto* agg2 = static_cast<typename Alg::S*>(buf->p);
+    hipLaunchKernelGGL((AggReduceKernel<Alg>), dim3(static_cast<unsigned>(nb2)), dim3(kBlock), 0, s, nb, agg, agg2);
+    hipLaunchKernelGGL((AggScanKernel<Alg>), dim3(1), dim3(kBlock), 0, s, nb2, agg2);
+    hipLaunchKernelGGL((AggApplyKernel<Alg>), dim3(static_cast<unsigned>(nb2)), dim3(kBlock), 0, s, nb, agg, agg2);
+  } else {
+    hipLaunchKernelGGL((AggScanKernel<Alg>), dim3(1), dim3(kBlock), 0, s, nb, agg);
+  }
+}
+
+// ---- tile scans ----------------------------------------------------------------------------------
+// A tile op provides: Alg (S, combine, identity), kItems, kRev, a register context Ctx and
+//   Load (tile, chunk, item[kItems], ctx)  block-cooperative (may synchronise): elements of the
+//                                          natural positions c0 .. c0+kItems-1, c0 = (tile*kBlock + chunk)*kItems
+//   Store(tile, chunk, incl[kItems], ctx)  inclusive results at the same natural positions.
+// Scan order is natural (kRev = false) or reversed; with kRev the tile / chunk the workgroup /
+// thread takes is mirrored, so that every thread still owns a contiguous, aligned chunk.
+
+template <class Op>
+__global__ __launch_bounds__(kBlock) void TileReduceKernel(Op op, int64_t nb, typename Op::Alg::S* agg) {
+  using Alg = typename Op::Alg;
+  using S = typename Alg::S;
+  __shared__ S lds[kBlock / 64];
+  const int64_t tile = Op::kRev ? nb - 1 - blockIdx.x : blockIdx.x;
+  const int chunk = Op::kRev ? kBlock - 1 - static_cast<int>(threadIdx.x) : static_cast<int>(threadIdx.x);
+  S item[Op::kItems];
+  typename Op::Ctx ctx;
+  op.Load(tile, chunk, item, ctx);
+  S acc = Alg::identity();
+#pragma unroll
+  for (int k = 0; k < Op::kItems; ++k) acc = Alg::combine(acc, item[Op::kRev ? Op::kItems - 1 - k : k]);
+  S total;
+  BlockExclusive<Alg>(acc, lds, &total);
+  if (threadIdx.x == 0) agg[blockIdx.x] = total;
+}
+
+template <class Op>
+__global__ __launch_bounds__(kBlock) void TileApplyKernel(Op op, int64_t nb, const typename Op::Alg::S* agg) {
+  using Alg = typename Op::Alg;
+  using S = typename Alg::S;
+  __shared__ S lds[kBlock / 64];
+  const int64_t tile = Op::kRev ? nb - 1 - blockIdx.x : blockIdx.x;
+  const int chunk = Op::kRev ? kBlock - 1 - static_cast<int>(threadIdx.x) : static_cast<int>(threadIdx.x);
+  S item[Op::kItems];
+  typename Op::Ctx ctx;
+  op.Load(tile, chunk, item, ctx);
+  S acc = Alg::identity();
+#pragma unroll
+  for (int k = 0; k < Op::kItems; ++k) acc = Alg::combine(acc, item[Op::kRev ? Op::kItems - 1 - k : k]);
+  S total;
+  const S excl = BlockExclusive<Alg>(acc, lds, &total);
+  S run = Alg::combine(agg[blockIdx.x], excl);
+#pragma unroll
+  for (int k = 0; k < Op::kItems; ++k) {
+    const int kk = Op::kRev ? Op::kItems - 1 - k : k;
+    run = Alg::combine(run, item[kk]);
+    item[kk] = run;
+  }
+  op.Store(tile, chunk, item, ctx);
+}
+
+template <class Op> void RunTileScan(const Op& op, int64_t n) {
+  if (n <= 0) return;
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  const int64_t tile = static_cast<int64_t>(kBlock) * Op::kItems;
+  const int64_t nb = (n + tile - 1) / tile;
+  using S = typename Op::Alg::S;
+  auto buf = rt.Alloc(static_cast<size_t>(nb) * sizeof(S));
+  S* agg = static_cast<S*>(buf->p);
+  hipLaunchKernelGGL((TileReduceKernel<Op>), dim3(static_cast<unsigned>(nb)), dim3(kBlock), 0, s, op, nb, agg);
+  RunAggScan<typename Op::Alg>(nb, agg);
+  hipLaunchKernelGGL((TileApplyKernel<Op>), dim3(static_cast<unsigned>(nb)), dim3(kBlock), 0, s, op, nb, agg);
+}
+
+// ---- vector access helpers -----------------------------------------------------------------------
+
+template <class T> struct Pack8;
+template <> struct Pack8<float> {
+  __device__ static void load(const float* p, float (&v)[8]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  __device__ static void store(float* p, const float (&v)[8]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Pack8<double> {
+  __device__ static void load(const double* p, double (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 a = reinterpret_cast<const double2*>(p)[q];
+      v[2 * q] = a.x;
+      v[2 * q + 1] = a.y;
+    }
+  }
+  __device__ static void store(double* p, const double (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) reinterpret_cast<double2*>(p)[q] = make_double2(v[2 * q], v[2 * q + 1]);
   }
 };
 
-struct EndScanOp {  // backward min of end positions -> new R
-  using S = int32_t;
-  const uint8_t* end;
-  const uint8_t* done;
-  int32_t* R;
-  __device__ S load(int64_t i) const { return end[i] ? static_cast<int32_t>(i) : 0x7fffffff; }
-  __device__ static S combine(S a, S b) { return a < b ? a : b; }
-  __device__ static S identity() { return 0x7fffffff; }
-  __device__ void store(int64_t i, S v) const {
-    if (!done[i]) R[i] = v;
+// ---- state byte ----------------------------------------------------------------------------------
+
+__device__ inline int SideSign(int code) { return code == 1 ? 1 : (code == 2 ? -1 : 0); }
+__device__ inline int SideCode(int sign) { return sign > 0 ? 1 : (sign < 0 ? 2 : 0); }
+constexpr int kHead = 1, kEnd = 2;
+
+// ---- prefix sums of y (fp64): Pp[i + 1] = sum_{k <= i} y_k, Pp[0] = 0 -----------------------------
+// (Pp points one double behind a 16-byte aligned buffer, so the 8 results of a chunk are aligned)
+
+template <class T> struct PrefixOp {
+  using Alg = SumAlg;
+  static constexpr int kItems = kFwdItems;
+  static constexpr bool kRev = false;
+  struct Ctx {};
+  const T* y;
+  double* Pp;
+  int64_t n;
+  bool aligned;
+  __device__ void Load(int64_t tile, int chunk, double (&item)[kItems], Ctx&) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    if (aligned && c0 + kItems <= n) {
+      T v[8];
+      Pack8<T>::load(y + c0, v);
+#pragma unroll
+      for (int k = 0; k < kItems; ++k) item[k] = static_cast<double>(v[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kItems; ++k) item[k] = c0 + k < n ? static_cast<double>(y[c0 + k]) : 0.0;
+    }
+  }
+  __device__ void Store(int64_t tile, int chunk, const double (&incl)[kItems], Ctx&) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    if (c0 + kItems <= n) {
+      Pack8<double>::store(Pp + c0 + 1, incl);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kItems; ++k)
+        if (c0 + k < n) Pp[c0 + k + 1] = incl[k];
+    }
   }
 };
 
-// ---- elementwise passes ------------------------------------------------------------------------
+// ---- the recursion's shared state ------------------------------------------------------------------
 
+template <class T> struct TvState {
+  const T* y;
+  T* x;
+  const double* Pp;        // prefix sums
+  uint8_t* st;             // state byte per sample (padded to a tile multiple)
+  uint8_t* st2;            // next level's state (written by the boundary scan)
+  double* tau_of;          // by region head
+  uint8_t* fin_of;         // by region head: the region did not split -> constant
+  int32_t* tile_head;      // per forward tile: last head position inside it (-1 none)
+  const int32_t* tile_l_in;  // per forward tile: last head position before it
+  unsigned long long* cuts;
+  double lam;
+  int64_t n;
+  bool aligned;            // y and x are 16-byte aligned
+};
+
+// forward clamp-shift scan
+template <class T, bool FLUSH> struct ClipOp {
+  using Alg = ClipAlg;
+  static constexpr int kItems = kFwdItems;
+  static constexpr bool kRev = false;
+  struct Ctx {
+    unsigned long long bytes;   // the 8 state bytes
+    unsigned fin_mask;          // samples whose region finished a level ago: x is written now
+    double tau[kItems];         // (only read where fin_mask is set)
+  };
+  TvState<T> s;
+
+  __device__ void Load(int64_t tile, int chunk, ClipMap (&item)[kItems], Ctx& ctx) const {
+    __shared__ int32_t lds[kBlock / 64];
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    const unsigned long long bytes = *reinterpret_cast<const unsigned long long*>(s.st + c0);
+    T yv[8];
+    if (s.aligned && c0 + kItems <= s.n) {
+      Pack8<T>::load(s.y + c0, yv);
+    } else {
+#pragma unroll
+      for (int k = 0; k < kItems; ++k) yv[k] = c0 + k < s.n ? s.y[c0 + k] : T(0);
+    }
+    // region head of every sample = running maximum of head positions
+    int32_t last = -1;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k)
+      if (((bytes >> (8 * k)) & kHead) && c0 + k < s.n) last = static_cast<int32_t>(c0 + k);
+    int32_t total;
+    int32_t l = BlockExclusive<MaxAlg>(last, lds, &total);
+    const int32_t lin = s.tile_l_in[tile];
+    l = l > lin ? l : lin;
+    ctx.bytes = bytes;
+    ctx.fin_mask = 0;
+    double tau = 0.0;
+    bool fin = false;
+    int32_t lrec = -2;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int64_t i = c0 + k;
+      const int b = static_cast<int>((bytes >> (8 * k)) & 0xff);
+      ctx.tau[k] = 0.0;
+      if (i >= s.n) {
+        item[k] = ClipAlg::identity();
+        continue;
+      }
+      if (b & kHead) l = static_cast<int32_t>(i);
+      const int cls = b >> 6;
+      if (cls == 3) {
+        item[k] = ClipMap{0.0, 0.0, 0.0};  // finished regions are inert
+        continue;
+      }
+      if (l != lrec) {
+        tau = s.tau_of[l];
+        fin = s.fin_of[l] != 0;
+        lrec = l;
+      }
+      if (fin || FLUSH) {
+        ctx.fin_mask |= 1u << k;
+        ctx.tau[k] = tau;
+        item[k] = ClipMap{0.0, 0.0, 0.0};
+        continue;
+      }
+      double yp = static_cast<double>(yv[k]);
+      if (b & kHead) yp -= s.lam * static_cast<double>(SideSign((b >> 2) & 3));
+      if (b & kEnd) yp -= s.lam * static_cast<double>(SideSign((b >> 4) & 3));
+      const double a = tau - yp;
+      item[k] = (b & kHead) ? ClipMap{0.0, a, a} : ClipMap{a, a - s.lam, a + s.lam};
+    }
+  }
+
+  __device__ void Store(int64_t tile, int chunk, const ClipMap (&incl)[kItems], Ctx& ctx) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    unsigned long long out = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int b = static_cast<int>((ctx.bytes >> (8 * k)) & 0xff);
+      int cls = b >> 6;
+      if (c0 + k < s.n && cls != 3) {
+        if (ctx.fin_mask & (1u << k)) {
+          cls = 3;
+        } else {
+          const ClipMap m = incl[k];
+          const double d = fmin(fmax(m.p, m.lo), m.hi);  // the composed map applied to 0
+          if (b & kEnd) cls = d < 0.0 ? 1 : 0;           // region end: definite
+          else if (d < -s.lam) cls = 1;
+          else if (d >= s.lam) cls = 0;
+          else cls = 2;
+        }
+      }
+      out |= static_cast<unsigned long long>((b & 0x3f) | (cls << 6)) << (8 * k);
+    }
+    *reinterpret_cast<unsigned long long*>(s.st + c0) = out;
+    if (ctx.fin_mask == 0xffu && s.aligned && c0 + kItems <= s.n) {
+      T xv[8];
+#pragma unroll
+      for (int k = 0; k < kItems; ++k) xv[k] = static_cast<T>(ctx.tau[k]);
+      Pack8<T>::store(s.x + c0, xv);
+    } else if (ctx.fin_mask) {
+#pragma unroll
+      for (int k = 0; k < kItems; ++k)
+        if (ctx.fin_mask & (1u << k)) s.x[c0 + k] = static_cast<T>(ctx.tau[k]);
+    }
+  }
+};
+
+// after the last level: write x for everything that is not written yet (no scan)
 template <class T>
-__global__ __launch_bounds__(kBlock) void TvInitKernel(TvState<T> st) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
-  if (i >= st.n) return;
-  st.L[i] = 0;
-  st.R[i] = static_cast<int32_t>(st.n - 1);
-  st.cl[i] = 0;
-  st.cr[i] = 0;
-  st.done[i] = 0;
+__global__ __launch_bounds__(kBlock) void TvFlushKernel(ClipOp<T, true> op) {
+  ClipMap item[kFwdItems];
+  typename ClipOp<T, true>::Ctx ctx;
+  op.Load(blockIdx.x, threadIdx.x, item, ctx);
+  op.Store(blockIdx.x, threadIdx.x, item, ctx);
 }
 
-// New boundaries of this level: where u changes inside a region.  split[l] = level marks the
-// region as not constant.
-template <class T>
-__global__ __launch_bounds__(kBlock) void TvSplitKernel(TvState<T> st, uint8_t* head,
-                                                        uint8_t* end, int8_t* cl2, int8_t* cr2,
-                                                        uint16_t* split, uint16_t level,
-                                                        unsigned long long* cuts) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
-  if (i >= st.n) return;
-  if (st.done[i]) {
-    head[i] = 0;
-    end[i] = 0;
-    return;
+// backward decode scan: u_i = first definite class at or to the right of i
+template <class T> struct DecodeOp {
+  using Alg = DecodeAlg;
+  static constexpr int kItems = kByteItems;
+  static constexpr bool kRev = true;
+  struct Ctx {
+    uint4 bytes;
+  };
+  TvState<T> s;
+  __device__ void Load(int64_t tile, int chunk, int (&item)[kItems], Ctx& ctx) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    ctx.bytes = *reinterpret_cast<const uint4*>(s.st + c0);
+    const unsigned w[4] = {ctx.bytes.x, ctx.bytes.y, ctx.bytes.z, ctx.bytes.w};
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int cls = static_cast<int>((w[k >> 2] >> (8 * (k & 3) + 6)) & 3);
+      item[k] = c0 + k < s.n ? (cls == 3 ? 0 : cls) : 2;
+    }
   }
-  const int32_t l = st.L[i], r = st.R[i];
-  const uint8_t ui = st.u[i];
-  const bool old_head = i == l, old_end = i == r;
-  const bool cut_left = !old_head && st.u[i - 1] != ui;
-  const bool cut_right = !old_end && st.u[i + 1] != ui;
-  head[i] = (old_head || cut_left) ? 1 : 0;
-  end[i] = (old_end || cut_right) ? 1 : 0;
-  // across a cut the u = 1 side lies strictly above the u = 0 side
-  cl2[i] = old_head ? st.cl[i] : (cut_left ? (ui ? int8_t(1) : int8_t(-1)) : int8_t(0));
-  cr2[i] = old_end ? st.cr[i] : (cut_right ? (ui ? int8_t(1) : int8_t(-1)) : int8_t(0));
-  if (cut_right) {
-    split[l] = level;
-    atomicAdd(cuts, 1ull);  // few: one per cut point of this level
+  __device__ void Store(int64_t tile, int chunk, const int (&incl)[kItems], Ctx& ctx) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    unsigned w[4] = {ctx.bytes.x, ctx.bytes.y, ctx.bytes.z, ctx.bytes.w};
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int sh = 8 * (k & 3) + 6;
+      const unsigned cls = (w[k >> 2] >> sh) & 3u;
+      if (cls != 3u && c0 + k < s.n)
+        w[k >> 2] = (w[k >> 2] & ~(3u << sh)) | (static_cast<unsigned>(incl[k] & 1) << sh);
+    }
+    *reinterpret_cast<uint4*>(s.st + c0) = make_uint4(w[0], w[1], w[2], w[3]);
   }
-}
+};
 
-// Regions that did not split are constant: write x = tau and retire them.
-template <class T>
-__global__ __launch_bounds__(kBlock) void TvFinishKernel(TvState<T> st, T* x,
-                                                         const uint16_t* split, uint16_t level) {
-  const int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
-  if (i >= st.n || st.done[i]) return;
-  const int32_t l = st.L[i], r = st.R[i];
-  if (split[l] != level) {
-    x[i] = static_cast<T>(st.Tau(l, r));
-    st.done[i] = 1;
+// backward boundary scan: nearest NEW end / nearest OLD end at or to the right of every sample
+template <class T> struct BoundOp {
+  using Alg = MinAlg;
+  static constexpr int kItems = kByteItems;
+  static constexpr bool kRev = true;
+  struct Ctx {
+    uint4 bytes;
+    unsigned new_head, new_end, cut_left, cut_right;  // bit k = sample c0 + k
+  };
+  TvState<T> s;
+  __device__ void Load(int64_t tile, int chunk, Int2 (&item)[kItems], Ctx& ctx) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    ctx.bytes = *reinterpret_cast<const uint4*>(s.st + c0);
+    const unsigned w[4] = {ctx.bytes.x, ctx.bytes.y, ctx.bytes.z, ctx.bytes.w};
+    const int bl = c0 > 0 ? s.st[c0 - 1] : 0;
+    const int br = c0 + kItems < s.n ? s.st[c0 + kItems] : 0;
+    ctx.new_head = ctx.new_end = ctx.cut_left = ctx.cut_right = 0;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int64_t i = c0 + k;
+      if (i >= s.n) {
+        item[k] = MinAlg::identity();
+        continue;
+      }
+      const int b = static_cast<int>((w[k >> 2] >> (8 * (k & 3))) & 0xff);
+      const int bprev = k > 0 ? static_cast<int>((w[(k - 1) >> 2] >> (8 * ((k - 1) & 3))) & 0xff) : bl;
+      const int bnext = k + 1 < kItems ? static_cast<int>((w[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xff) : br;
+      const int cls = b >> 6;
+      const bool active = cls != 3;
+      const bool head = b & kHead, end = b & kEnd;
+      // inside a region (not across its old boundary) both neighbours are active too
+      const bool cr = active && !end && ((bnext >> 6) & 1) != (cls & 1);
+      const bool cl = active && !head && ((bprev >> 6) & 1) != (cls & 1);
+      if (head || cl) ctx.new_head |= 1u << k;
+      if (end || cr) ctx.new_end |= 1u << k;
+      if (cl) ctx.cut_left |= 1u << k;
+      if (cr) ctx.cut_right |= 1u << k;
+      item[k] = Int2{(end || cr) ? static_cast<int32_t>(i) : kInf, end ? static_cast<int32_t>(i) : kInf};
+    }
   }
+  __device__ void Store(int64_t tile, int chunk, const Int2 (&incl)[kItems], Ctx& ctx) const {
+    const int64_t c0 = (tile * kBlock + chunk) * kItems;
+    const unsigned w[4] = {ctx.bytes.x, ctx.bytes.y, ctx.bytes.z, ctx.bytes.w};
+    unsigned o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int64_t i = c0 + k;
+      if (i >= s.n) continue;
+      const int b = static_cast<int>((w[k >> 2] >> (8 * (k & 3))) & 0xff);
+      const int cls = b >> 6;
+      const bool active = cls != 3;
+      const int u = cls & 1;
+      const bool nh = ctx.new_head & (1u << k), ne = ctx.new_end & (1u << k);
+      // across a cut the u = 1 side lies strictly above the u = 0 side
+      int clc = (b & kHead) ? ((b >> 2) & 3) : ((ctx.cut_left & (1u << k)) ? SideCode(u ? 1 : -1) : 0);
+      int crc = (b & kEnd) ? ((b >> 4) & 3) : ((ctx.cut_right & (1u << k)) ? SideCode(u ? 1 : -1) : 0);
+      const int nb = (nh ? kHead : 0) | (ne ? kEnd : 0) | (clc << 2) | (crc << 4) | (active ? 0 : (3 << 6));
+      o[k >> 2] |= static_cast<unsigned>(nb) << (8 * (k & 3));
+      if (nh && active) {
+        // region record of the new region [i, r]
+        const int32_t r = incl[k].a;
+        const int brr = s.st[r];
+        const int cr_sign = (brr & kEnd) ? SideSign((brr >> 4) & 3) : (((brr >> 6) & 1) ? 1 : -1);
+        const double tot = s.Pp[static_cast<int64_t>(r) + 1] - s.Pp[i] -
+                           s.lam * static_cast<double>(SideSign(clc) + cr_sign);
+        s.tau_of[i] = tot / static_cast<double>(r - static_cast<int32_t>(i) + 1);
+        s.fin_of[i] = ((b & kHead) && incl[k].a == incl[k].b) ? 1 : 0;
+        atomicMax(&s.tile_head[i / kFwdTile], static_cast<int32_t>(i));
+      }
+    }
+    *reinterpret_cast<uint4*>(s.st2 + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+    const int ncut = __popc(ctx.cut_right);
+    if (ncut) atomicAdd(s.cuts, static_cast<unsigned long long>(ncut));  // few: one per cut point
+  }
+};
+
+template <class T>
+__global__ void TvInitKernel(TvState<T> s, int32_t* tile_head) {
+  // one region [0, n-1] without neighbours
+  s.st[0] = static_cast<uint8_t>(s.st[0] | kHead);
+  s.st[s.n - 1] = static_cast<uint8_t>(s.st[s.n - 1] | kEnd);
+  s.tau_of[0] = s.Pp[s.n] / static_cast<double>(s.n);
+  s.fin_of[0] = 0;
+  tile_head[0] = 0;
 }
 
 template <class T> int Tv1dLevelSets(const DVec& xv, const DVec& yv, double lam) {
@@ -363,64 +605,69 @@ template <class T> int Tv1dLevelSets(const DVec& xv, const DVec& yv, double lam)
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   ProfScope prof("tv1d", n);
-  auto alloc = [&](size_t bytes) { return rt.Alloc(bytes); };
-  auto bP = alloc((n + 1) * sizeof(double));
-  auto bL = alloc(n * sizeof(int32_t)), bR = alloc(n * sizeof(int32_t));
-  auto bcl = alloc(n), bcr = alloc(n), bcl2 = alloc(n), bcr2 = alloc(n);
-  auto bdone = alloc(n), bs = alloc(n), bu = alloc(n), bhead = alloc(n), bend = alloc(n);
-  auto bsplit = alloc(n * sizeof(uint16_t));
-  auto bcount = alloc(sizeof(unsigned long long));
-  double* P = static_cast<double*>(bP->p);
-  EPS_HIP(hipMemsetAsync(P, 0, sizeof(double), s));
-  EPS_HIP(hipMemsetAsync(bsplit->p, 0, n * sizeof(uint16_t), s));
-  PrefixSumOp<T> ps{yv.as<T>(), P};
-  RunScan<PrefixSumOp<T>, false>(ps, n);
+  const int64_t byte_tile = static_cast<int64_t>(kBlock) * kByteItems;
+  const int64_t npad = (n + byte_tile - 1) / byte_tile * byte_tile;  // multiple of both tile sizes
+  const int64_t nft = npad / kFwdTile;                               // forward tiles
+  auto bP = rt.Alloc((static_cast<size_t>(npad) + 4) * sizeof(double));
+  auto bst = rt.Alloc(npad), bst2 = rt.Alloc(npad);
+  auto btau = rt.Alloc(static_cast<size_t>(n) * sizeof(double));
+  auto bfin = rt.Alloc(n);
+  auto bth = rt.Alloc(static_cast<size_t>(nft) * sizeof(int32_t));
+  auto btl = rt.Alloc(static_cast<size_t>(nft) * sizeof(int32_t));
+  auto bcount = rt.Alloc(sizeof(unsigned long long));
+  double* Pp = static_cast<double*>(bP->p) + 1;  // Pp + 1 is 16-byte aligned
+  EPS_HIP(hipMemsetAsync(Pp, 0, sizeof(double), s));
+  const bool aligned = reinterpret_cast<uintptr_t>(yv.data()) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(xv.data()) % 16 == 0;
+  PrefixOp<T> pop{yv.as<T>(), Pp, n, aligned};
+  RunTileScan(pop, n);
 
   TvState<T> st;
   st.y = yv.as<T>();
-  st.P = P;
-  st.L = static_cast<int32_t*>(bL->p);
-  st.R = static_cast<int32_t*>(bR->p);
-  st.cl = static_cast<int8_t*>(bcl->p);
-  st.cr = static_cast<int8_t*>(bcr->p);
-  st.done = static_cast<uint8_t*>(bdone->p);
-  st.s = static_cast<uint8_t*>(bs->p);
-  st.u = static_cast<uint8_t*>(bu->p);
+  st.x = xv.as<T>();
+  st.Pp = Pp;
+  st.st = static_cast<uint8_t*>(bst->p);
+  st.st2 = static_cast<uint8_t*>(bst2->p);
+  st.tau_of = static_cast<double*>(btau->p);
+  st.fin_of = static_cast<uint8_t*>(bfin->p);
+  st.tile_head = static_cast<int32_t*>(bth->p);
+  int32_t* tile_l_in = static_cast<int32_t*>(btl->p);
+  st.tile_l_in = tile_l_in;
+  st.cuts = static_cast<unsigned long long*>(bcount->p);
   st.lam = lam;
   st.n = n;
-  int8_t* cl2 = static_cast<int8_t*>(bcl2->p);
-  int8_t* cr2 = static_cast<int8_t*>(bcr2->p);
-  uint8_t* head = static_cast<uint8_t*>(bhead->p);
-  uint8_t* end = static_cast<uint8_t*>(bend->p);
-  uint16_t* split = static_cast<uint16_t*>(bsplit->p);
-  auto* remaining = static_cast<unsigned long long*>(bcount->p);
-  const unsigned grid = static_cast<unsigned>((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(TvInitKernel<T>, dim3(grid), dim3(kBlock), 0, s, st);
+  st.aligned = aligned;
+  EPS_HIP(hipMemsetAsync(st.st, 0, npad, s));
+  EPS_HIP(hipMemsetAsync(st.st2, 0, npad, s));
+  EPS_HIP(hipMemsetAsync(st.tile_head, 0xff, static_cast<size_t>(nft) * sizeof(int32_t), s));
+  hipLaunchKernelGGL(TvInitKernel<T>, dim3(1), dim3(1), 0, s, st, st.tile_head);
 
+  auto head_prescan = [&] {
+    EPS_HIP(hipMemcpyAsync(tile_l_in, st.tile_head, static_cast<size_t>(nft) * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, s));
+    RunAggScan<MaxAlg>(nft, tile_l_in);
+  };
   int level = 0;
   for (;;) {
     ++level;
     EPS_CHECK_MSG(level < 60000, "tv1d: level-set recursion did not terminate");
-    ClipScanOp<T> cop{st};
-    RunScan<ClipScanOp<T>, false>(cop, n);
-    DecodeScanOp<T> dop{st};
-    RunScan<DecodeScanOp<T>, true>(dop, n);
-    EPS_HIP(hipMemsetAsync(remaining, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(TvSplitKernel<T>, dim3(grid), dim3(kBlock), 0, s, st, head, end, cl2, cr2,
-                       split, static_cast<uint16_t>(level), remaining);
-    hipLaunchKernelGGL(TvFinishKernel<T>, dim3(grid), dim3(kBlock), 0, s, st, xv.as<T>(), split,
-                       static_cast<uint16_t>(level));
+    head_prescan();
+    RunTileScan(ClipOp<T, false>{st}, n);
+    RunTileScan(DecodeOp<T>{st}, n);
+    EPS_HIP(hipMemsetAsync(st.cuts, 0, sizeof(unsigned long long), s));
+    EPS_HIP(hipMemsetAsync(st.tile_head, 0xff, static_cast<size_t>(nft) * sizeof(int32_t), s));
+    RunTileScan(BoundOp<T>{st}, n);
+    std::swap(st.st, st.st2);
     unsigned long long h = 0;
-    EPS_HIP(hipMemcpyAsync(&h, remaining, sizeof(h), hipMemcpyDeviceToHost, s));
+    EPS_HIP(hipMemcpyAsync(&h, st.cuts, sizeof(h), hipMemcpyDeviceToHost, s));
     EPS_HIP(hipStreamSynchronize(s));
     if (h == 0) break;
-    HeadScanOp hop{head, st.done, st.L};
-    RunScan<HeadScanOp, false>(hop, n);
-    EndScanOp eop{end, st.done, st.R};
-    RunScan<EndScanOp, true>(eop, n);
-    std::swap(st.cl, cl2);
-    std::swap(st.cr, cr2);
   }
+  // every remaining region carries "finished" now: write their x
+  head_prescan();
+  hipLaunchKernelGGL(TvFlushKernel<T>, dim3(static_cast<unsigned>(nft)), dim3(kBlock), 0, s,
+                     ClipOp<T, true>{st});
+  EPS_HIP(hipGetLastError());
   return level;
 }
 

@@ -24,9 +24,10 @@ def column_range(n, rank, world, align=64):
     return lo, hi
 
 
-def init_comm(rank, world, backend="rccl"):
+def init_comm(rank, world, backend="rccl", peer=False, slot_floats=0):
     """Collective: set up the solver library's communicator.  Needs torch.distributed to be
-    initialised (any backend) for the rendezvous."""
+    initialised (any backend) for the rendezvous.  peer=True also tries to set up the one-shot
+    peer-write window for the per-sweep messages; returns (enabled, reason)."""
     import torch.distributed as dist
     if backend == "rccl":
         obj = [_solve.comm_unique_id() if rank == 0 else None]
@@ -46,6 +47,9 @@ def init_comm(rank, world, backend="rccl"):
         _solve.comm_init_callback(rank, world, allreduce)
     else:
         raise ValueError(backend)
+    if peer:
+        return _solve.comm_enable_peer(slot_floats)
+    return False, "not requested"
 
 
 def lasso_sharded_keys(prob):

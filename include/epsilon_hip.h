@@ -145,6 +145,19 @@ int eps_comm_init_callback(int rank, int world, eps_allreduce_fn fn, void* ctx);
 /* One all-reduce + one all-gather of `count` floats over the communicator, checked (sum of ones
  * == world size): a barrier that also takes RCCL's first-use setup out of a timed Init. */
 int eps_comm_warmup(size_t count);
+/* COLLECTIVE, optional, after eps_comm_init_*: a one-shot peer-write exchange window over the
+ * direct xGMI links (HIP IPC) for the per-sweep messages of a column-sharded solve - m floats
+ * each, latency-bound.  With it the sharded fused sweep makes no collective call
+ * at all: every rank writes its part straight into every peer's window from inside the sweep's
+ * own kernels and sums what it received in rank order (csrc/kernels_peer.hip), and the sweeps
+ * between two residual checks are replayed from one hipGraph.  The communicator above stays in
+ * charge of the large setup messages and of the residual scalars.  `slot_floats` = largest
+ * message (0: 16384); `rehearse_ranks` > 1 (single-rank communicator only) makes this process
+ * play ONE rank of that many for timing rehearsals on one GPU (results are not a solve's).
+ * *enabled = 1 if every rank has the window and its self test passed, else 0 - then nothing
+ * changes (RCCL per sweep) and eps_last_error() says why.  The reference has no counterpart
+ * (it has no distributed mode). */
+int eps_comm_enable_peer(size_t slot_floats, int rehearse_ranks, int* enabled);
 int eps_comm_shutdown(void);
 /* Replace the set of sharded block keys (variable ids and "constraint:<i>" rows). */
 int eps_shard_keys(const char* const* keys, size_t nkeys);

@@ -48,6 +48,24 @@ def lasso_run(A, Minv, b, lam, state, k, abs_tol=1e-4, rel_tol=1e-2, epoch=10):
     return done
 
 
+def set_threads(t):
+    """Threads of the mat-vecs in lasso_run (1 = the reference's configuration)."""
+    lib().oracle_set_threads(ctypes.c_int(int(t)))
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+def gram(A):
+    """A A^T by the plain-C blocked contraction (Init timing sample of bench.py)."""
+    m, n = A.shape
+    assert A.flags.f_contiguous
+    G = np.empty((m, m), order="F")
+    lib().gram_aat(ctypes.c_int(m), ctypes.c_int(n), _p(A), _p(G))
+    return G
+
+
 def tv1d(y, lam):
     y = np.ascontiguousarray(y, dtype=np.float64)
     out = np.empty_like(y)

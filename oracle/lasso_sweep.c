@@ -16,22 +16,86 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads for the three mat-vecs (1 = the reference's own configuration; bench.py also times
+ * all host cores).  The arithmetic per output element is the same chain of operations for any
+ * thread count - rows of y (N form) and columns (T form) are dealt to the threads whole - so the
+ * iterates do not depend on it. */
+static int g_threads = 1;
+void oracle_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 static void gemv_n(int m, int n, const double* A, const double* x, double* y) {
-  memset(y, 0, sizeof(double) * (size_t)m);
-  for (int j = 0; j < n; ++j) {
-    const double xj = x[j];
-    const double* a = A + (size_t)j * m;
-    for (int i = 0; i < m; ++i) y[i] += a[i] * xj;
+  /* each thread owns a block of rows and streams all columns through it */
+#pragma omp parallel num_threads(g_threads)
+  {
+    int nt = 1, id = 0;
+#ifdef _OPENMP
+    nt = omp_get_num_threads();
+    id = omp_get_thread_num();
+#endif
+    const int per = ((m + nt - 1) / nt + 7) / 8 * 8;
+    const int i0 = id * per < m ? id * per : m;
+    const int i1 = i0 + per < m ? i0 + per : m;
+    if (i1 > i0) {
+      memset(y + i0, 0, sizeof(double) * (size_t)(i1 - i0));
+      for (int j = 0; j < n; ++j) {
+        const double xj = x[j];
+        const double* a = A + (size_t)j * m;
+        for (int i = i0; i < i1; ++i) y[i] += a[i] * xj;
+      }
+    }
   }
 }
 
 static void gemv_t(int m, int n, const double* A, const double* x, double* y) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
   for (int j = 0; j < n; ++j) {
     const double* a = A + (size_t)j * m;
     double s = 0;
     for (int i = 0; i < m; ++i) s += a[i] * x[i];
     y[j] = s;
+  }
+}
+
+/* G = A A^T (m x m, both triangles) for column-major A (m x n): the contraction the reference
+ * hands to dgemm_ at Init (linear/linear_map_multiply.cc:14-37).  Plain cache-blocked C - 64 x 64
+ * blocks of G accumulated over all columns - used by bench.py to time the CPU's Init on a
+ * reduced instance; threads as in the mat-vecs. */
+void gram_aat(int m, int n, const double* A, double* G) {
+  const int B = 64;
+  const int nb = (m + B - 1) / B;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+  for (int t = 0; t < nb * nb; ++t) {
+    const int bi = t / nb, bj = t % nb;
+    if (bj > bi) continue;
+    const int i0 = bi * B, j0 = bj * B;
+    const int ni = m - i0 < B ? m - i0 : B, nj = m - j0 < B ? m - j0 : B;
+    double acc[64][64];
+    for (int q = 0; q < nj; ++q)
+      for (int p = 0; p < ni; ++p) acc[q][p] = 0;
+    for (int k = 0; k < n; ++k) {
+      const double* ai = A + (size_t)k * m + i0;
+      const double* aj = A + (size_t)k * m + j0;
+      for (int q = 0; q < nj; ++q) {
+        const double v = aj[q];
+        for (int p = 0; p < ni; ++p) acc[q][p] += ai[p] * v;
+      }
+    }
+    for (int q = 0; q < nj; ++q)
+      for (int p = 0; p < ni; ++p) {
+        G[(size_t)(j0 + q) * m + i0 + p] = acc[q][p];
+        G[(size_t)(i0 + p) * m + j0 + q] = acc[q][p];
+      }
   }
 }
 

@@ -238,7 +238,9 @@ def main():
         from epsilon_amd import _solve
         dtype = os.environ.get("EPS_TEST_DTYPE", "f64")
         _solve.set_option("dtype", dtype)
-        edist.init_comm(rank, world, backend="host")
+        want_peer = os.environ.get("EPS_TEST_PEER") == "1"
+        on, why = edist.init_comm(rank, world, backend="host", peer=want_peer)
+        assert on == want_peer, why
         prob = problems.lasso_ir(ir.dense_matrix(Ag), ir.constant(b), lam, ng)
         edist.mark_sharded(None, prob)
         params = wire.SolverParams(max_iterations=max_iter)

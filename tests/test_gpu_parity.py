@@ -672,6 +672,53 @@ def test_fused_sweep_sharded(solve_mod, tmp_path, apply_mode):
     np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("world,apply_mode,graph", [(2, "slab", "1"), (3, "slab", "0"), (3, "slab", "1"),
+                                                    (3, "replicated", "1")])
+def test_fused_sweep_sharded_peer_window(solve_mod, tmp_path, world, apply_mode, graph):
+    """The same solve with the per-sweep exchanges on the one-shot peer-write window
+    (csrc/kernels_peer.hip): ranks are separate processes sharing this GPU, their windows are
+    mapped into each other through HIP IPC, every rank writes its partial forward product / its
+    slab of w straight into the peers' windows from inside the sweep's kernels; sweeps between
+    residual checks eager (graph 0) or replayed from a hipGraph (graph 1)."""
+    from tests import mp_util
+    m, n = 40, 101
+    x0, x1, status, parts = mp_util.run_ranks(world, "hip", str(tmp_path), m, n, seed=3,
+                                              env_extra={"EPS_TEST_DTYPE": "f32", "EPS_TEST_PEER": "1",
+                                                         "EPSILON_HIP_GRAPH": graph,
+                                                         "EPSILON_HIP_SHARDED_APPLY": apply_mode})
+    prob, info = problems.lasso(m, n, seed=3)
+    st, x = orc.solve(prob.SerializeToString(), [], wire.SolverParams().SerializeToString(),
+                      prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    for s, p in zip(status, parts):
+        assert int(p["state"]) == wire.SolverStatus.OPTIMAL and int(s[0]) == S.num_iterations
+    np.testing.assert_allclose(x0, np.frombuffer(x[problems.LASSO_COPY]), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=1e-3, atol=1e-4)
+
+
+def test_peer_window_graph_replay_is_bit_identical(solve_mod, tmp_path):
+    """45 sweeps through the exchange kernels, once launched eagerly and once replayed from
+    hipGraphs of the sweeps between residual checks: the iterates must agree bit for bit; plus
+    the oracle comparison and the rank-of-8 rehearsal window (tests/peer_single_rank.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    fe, fg = str(tmp_path / "eager.npz"), str(tmp_path / "graph.npz")
+    env = dict(os.environ, MASTER_PORT="29641")
+    r1 = subprocess.run([sys.executable, os.path.join(here, "peer_single_rank.py"), "eager", fe],
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0 and "PEER_EAGER_DONE" in r1.stdout, r1.stdout[-2000:] + r1.stderr[-3000:]
+    env = dict(os.environ, MASTER_PORT="29642")
+    r2 = subprocess.run([sys.executable, os.path.join(here, "peer_single_rank.py"), "graph", fg],
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert r2.returncode == 0 and "PEER_OK" in r2.stdout, r2.stdout[-2000:] + r2.stderr[-3000:]
+    a, b = np.load(fe), np.load(fg)
+    assert sorted(a.files) == sorted(b.files) and a.files
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("shape", [(3, 3), (12, 7), (7, 12), (40, 25), (1, 5)])
 def test_nuclear_norm_prox(solve_mod, dtype, shape):
     """NORM_NUCLEAR (reference prox_test.py:190; prox/ortho_invariant.cc): one-sided Jacobi SVD
