@@ -611,6 +611,28 @@ int eps_bench_spd_inverse_columns(int64_t n, int64_t cnt, int iters, double* ms_
   });
 }
 
+int eps_bench_prox(int kind, int64_t n, int iters, double* ms_avg) {
+  return Guard([&] {
+    EPS_CHECK(n > 0 && iters > 0 && ms_avg != nullptr);
+    const DType dt = ConfiguredDType();
+    DVec v = Synthetic(n, dt, 4.0);
+    DVec x = DVec::Empty(n, dt);
+    k::ScaledZoneArgs a;
+    a.lam = 0.7;
+    DVec lamv;
+    if (kind == 1) {  // per-element thresholds (weighted norm_1, quantile)
+      lamv = Synthetic(n, dt, 1.0);
+      k::Axpby(lamv, 0.0, lamv, 1.0);
+      k::Fill(lamv, 0.7);
+      a.lam_vec = &lamv;
+    }
+    *ms_avg = TimeLaunches(iters, [&] {
+      if (kind == 2) k::MaxZero(x, v);
+      else k::ScaledZone(x, v, a);
+    });
+  });
+}
+
 int eps_tv1d(const double* v, size_t n, double lam, double* x) {
   return Guard([&] {
     const DType dt = ConfiguredDType();

@@ -28,47 +28,148 @@ inline int GridFor(int64_t n) {
   return static_cast<int>(g);
 }
 
+// 16 bytes per lane and access: V = 4 floats / 2 doubles.
+template <class T> struct VecOf;
+template <> struct VecOf<float> {
+  static constexpr int V = 4;
+  typedef float4 type;
+  __device__ static void unpack(const float4& p, float (&e)[4]) { e[0] = p.x; e[1] = p.y; e[2] = p.z; e[3] = p.w; }
+  __device__ static float4 pack(const float (&e)[4]) { return make_float4(e[0], e[1], e[2], e[3]); }
+};
+template <> struct VecOf<double> {
+  static constexpr int V = 2;
+  typedef double2 type;
+  __device__ static void unpack(const double2& p, double (&e)[2]) { e[0] = p.x; e[1] = p.y; }
+  __device__ static double2 pack(const double (&e)[2]) { return make_double2(e[0], e[1]); }
+};
+
+// reference prox/scaled_zone.cc:90-101, one element: the branch order is the reference's, so
+// the branch taken - and with it the result - is the same for the same operands
+template <class T> __device__ inline T ScaledZoneElem(T vi, T C, T M, T lam, T alpha, T beta) {
+  const T xi = vi - C;
+  if (fabs(xi) <= M) return xi;
+  if (xi > M + lam * alpha) return xi - lam * alpha;
+  if (xi < -M - lam * beta) return xi + lam * beta;
+  if (xi > T(0)) return M;
+  return -M;
+}
+
+// Vector form: every array is read / written 16 bytes per lane (the caller guarantees the
+// alignment and period == 0); UNROLL independent accesses per thread are in flight.  PV says
+// which of lam / alpha / beta are per-element vectors (bit 0 / 1 / 2).
+template <class T, int PV>
+__global__ __launch_bounds__(kBlock) void ScaledZoneVecKernel(
+    T* __restrict__ x, const T* __restrict__ v, int64_t nvec, T lam_s, T alpha_s, T beta_s, T M, T C,
+    const T* __restrict__ lam_v, const T* __restrict__ alpha_v, const T* __restrict__ beta_v) {
+  using VT = typename VecOf<T>::type;
+  constexpr int V = VecOf<T>::V;
+  constexpr int UNROLL = 4;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+  for (int64_t q0 = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x; q0 < nvec; q0 += stride * UNROLL) {
+    VT pv[UNROLL], pl[UNROLL], pa[UNROLL], pb[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t q = q0 + u * stride;
+      if (q < nvec) {
+        pv[u] = reinterpret_cast<const VT*>(v)[q];
+        if (PV & 1) pl[u] = reinterpret_cast<const VT*>(lam_v)[q];
+        if (PV & 2) pa[u] = reinterpret_cast<const VT*>(alpha_v)[q];
+        if (PV & 4) pb[u] = reinterpret_cast<const VT*>(beta_v)[q];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t q = q0 + u * stride;
+      if (q < nvec) {
+        T ev[V], el[V], ea[V], eb[V], eo[V];
+        VecOf<T>::unpack(pv[u], ev);
+        if (PV & 1) VecOf<T>::unpack(pl[u], el);
+        if (PV & 2) VecOf<T>::unpack(pa[u], ea);
+        if (PV & 4) VecOf<T>::unpack(pb[u], eb);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          eo[e] = ScaledZoneElem<T>(ev[e], C, M, (PV & 1) ? el[e] : lam_s, (PV & 2) ? ea[e] : alpha_s,
+                                    (PV & 4) ? eb[e] : beta_s);
+        reinterpret_cast<VT*>(x)[q] = VecOf<T>::pack(eo);
+      }
+    }
+  }
+}
+
+// General form (tails, unaligned buffers, periodic parameter vectors).  The periodic index is
+// advanced by the stride modulo the period instead of a 64-bit division per element.
 template <class T>
 __global__ __launch_bounds__(kBlock) void ScaledZoneKernel(
-    T* x, const T* v, int64_t n, T lam_s, T alpha_s, T beta_s, T M, T C, const T* lam_v,
+    T* x, const T* v, int64_t i0, int64_t n, T lam_s, T alpha_s, T beta_s, T M, T C, const T* lam_v,
     const T* alpha_v, const T* beta_v, int64_t period) {
-  const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+  const int64_t tid = i0 + blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  int64_t pi = period > 0 ? tid % period : 0;
+  const int64_t pstep = period > 0 ? stride % period : 0;
   for (int64_t i = tid; i < n; i += stride) {
-    const int64_t pi = period > 0 ? (i % period) : i;
-    const T lam = lam_v ? lam_v[pi] : lam_s;
-    const T alpha = alpha_v ? alpha_v[pi] : alpha_s;
-    const T beta = beta_v ? beta_v[pi] : beta_s;
-    T xi = v[i] - C;
-    T out;
-    if (fabs(xi) <= M) out = xi;
-    else if (xi > M + lam * alpha) out = xi - lam * alpha;
-    else if (xi < -M - lam * beta) out = xi + lam * beta;
-    else if (xi > T(0)) out = M;
-    else out = -M;
-    x[i] = out;
+    const int64_t k = period > 0 ? pi : i;
+    const T lam = lam_v ? lam_v[k] : lam_s;
+    const T alpha = alpha_v ? alpha_v[k] : alpha_s;
+    const T beta = beta_v ? beta_v[k] : beta_s;
+    x[i] = ScaledZoneElem<T>(v[i], C, M, lam, alpha, beta);
+    if (period > 0) {
+      pi += pstep;
+      if (pi >= period) pi -= period;
+    }
   }
 }
 
 template <class T>
-__global__ __launch_bounds__(kBlock) void MaxZeroKernel(T* x, const T* v, int64_t n) {
+__global__ __launch_bounds__(kBlock) void MaxZeroKernel(T* __restrict__ x, const T* __restrict__ v,
+                                                        int64_t n, bool vec) {
+  using VT = typename VecOf<T>::type;
+  constexpr int V = VecOf<T>::V;
   const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = tid; i < n; i += stride) {
+  const int64_t nvec = vec ? n / V : 0;
+  constexpr int UNROLL = 4;
+  for (int64_t q0 = tid; q0 < nvec; q0 += stride * UNROLL) {
+    VT pv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (q0 + u * stride < nvec) pv[u] = reinterpret_cast<const VT*>(v)[q0 + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (q0 + u * stride < nvec) {
+        T e[V];
+        VecOf<T>::unpack(pv[u], e);
+#pragma unroll
+        for (int k = 0; k < V; ++k) e[k] = e[k] > T(0) ? e[k] : T(0);  // non_negative.cc:8
+        reinterpret_cast<VT*>(x)[q0 + u * stride] = VecOf<T>::pack(e);
+      }
+    }
+  }
+  for (int64_t i = nvec * V + tid; i < n; i += stride) {
     const T vi = v[i];
     x[i] = vi > T(0) ? vi : T(0);
   }
 }
 
 template <class T>
-__global__ __launch_bounds__(kBlock) void Norm2ShrinkKernel(T* x, const T* v, int64_t n,
-                                                            double lam, const double* normsq) {
+__global__ __launch_bounds__(kBlock) void Norm2ShrinkKernel(T* __restrict__ x, const T* __restrict__ v,
+                                                            int64_t n, double lam,
+                                                            const double* normsq, bool vec) {
+  using VT = typename VecOf<T>::type;
+  constexpr int V = VecOf<T>::V;
   const double nv = sqrt(*normsq);
   const T scale = (nv >= lam) ? static_cast<T>(1.0 - lam / nv) : T(0);
   const bool zero = !(nv >= lam);
   const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
   const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = tid; i < n; i += stride) x[i] = zero ? T(0) : scale * v[i];
+  const int64_t nvec = vec ? n / V : 0;
+  for (int64_t q = tid; q < nvec; q += stride) {
+    T e[V];
+    VecOf<T>::unpack(reinterpret_cast<const VT*>(v)[q], e);
+#pragma unroll
+    for (int k = 0; k < V; ++k) e[k] = zero ? T(0) : scale * e[k];
+    reinterpret_cast<VT*>(x)[q] = VecOf<T>::pack(e);
+  }
+  for (int64_t i = nvec * V + tid; i < n; i += stride) x[i] = zero ? T(0) : scale * v[i];
 }
 
 // ---- exact 1-D TV prox ---------------------------------------------------------------------
@@ -146,6 +247,45 @@ __global__ void Tv1dSerialKernel(T* beta, const T* y, int64_t n, double lam, dou
 
 }  // namespace
 
+namespace {
+
+inline bool Aligned16(const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; }
+
+template <class T> void LaunchScaledZone(const DVec& x, const DVec& v, const ScaledZoneArgs& g) {
+  using VTr = VecOf<T>;
+  const int64_t n = x.n;
+  hipStream_t s = Runtime::Get().stream();
+  const T* lv = g.lam_vec ? g.lam_vec->as<T>() : nullptr;
+  const T* av = g.alpha_vec ? g.alpha_vec->as<T>() : nullptr;
+  const T* bv = g.beta_vec ? g.beta_vec->as<T>() : nullptr;
+  int64_t done = 0;
+  const bool vec_ok = g.period == 0 && Aligned16(x.data()) && Aligned16(v.data()) &&
+                      (!lv || Aligned16(lv)) && (!av || Aligned16(av)) && (!bv || Aligned16(bv));
+  const int64_t nvec = vec_ok ? n / VTr::V : 0;
+  if (nvec > 0) {
+    const int pvm = (lv ? 1 : 0) | (av ? 2 : 0) | (bv ? 4 : 0);
+    int64_t grid = (nvec + kBlock * 4 - 1) / (kBlock * 4);
+    if (grid > 4096) grid = 4096;
+#define EPS_SZ_CASE(PVV)                                                                          \
+  case PVV:                                                                                       \
+    hipLaunchKernelGGL((ScaledZoneVecKernel<T, PVV>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, s, \
+                       x.as<T>(), v.as<T>(), nvec, T(g.lam), T(g.alpha), T(g.beta), T(g.M), T(g.C), lv, av, bv); \
+    break;
+    switch (pvm) {
+      EPS_SZ_CASE(0) EPS_SZ_CASE(1) EPS_SZ_CASE(2) EPS_SZ_CASE(3) EPS_SZ_CASE(4) EPS_SZ_CASE(5)
+      EPS_SZ_CASE(6) EPS_SZ_CASE(7)
+    }
+#undef EPS_SZ_CASE
+    done = nvec * VTr::V;
+  }
+  if (done < n)
+    hipLaunchKernelGGL(ScaledZoneKernel<T>, dim3(GridFor(n - done)), dim3(kBlock), 0, s, x.as<T>(),
+                       v.as<T>(), done, n, T(g.lam), T(g.alpha), T(g.beta), T(g.M), T(g.C), lv, av, bv,
+                       g.period);
+}
+
+}  // namespace
+
 void ScaledZone(const DVec& x, const DVec& v, const ScaledZoneArgs& g) {
   EPS_CHECK(x.n == v.n && x.dt == v.dt);
   const int64_t n = x.n;
@@ -154,46 +294,40 @@ void ScaledZone(const DVec& x, const DVec& v, const ScaledZoneArgs& g) {
   if (g.lam_vec) EPS_CHECK(g.lam_vec->n >= need && g.lam_vec->dt == x.dt);
   if (g.alpha_vec) EPS_CHECK(g.alpha_vec->n >= need && g.alpha_vec->dt == x.dt);
   if (g.beta_vec) EPS_CHECK(g.beta_vec->n >= need && g.beta_vec->dt == x.dt);
-  hipStream_t s = Runtime::Get().stream();
-  if (x.dt == F32) {
-    using T = float;
-    hipLaunchKernelGGL(ScaledZoneKernel<T>, dim3(GridFor(n)), dim3(kBlock), 0, s, x.as<T>(),
-                       v.as<T>(), n, T(g.lam), T(g.alpha), T(g.beta), T(g.M), T(g.C),
-                       g.lam_vec ? g.lam_vec->as<T>() : nullptr,
-                       g.alpha_vec ? g.alpha_vec->as<T>() : nullptr,
-                       g.beta_vec ? g.beta_vec->as<T>() : nullptr, g.period);
-  } else {
-    using T = double;
-    hipLaunchKernelGGL(ScaledZoneKernel<T>, dim3(GridFor(n)), dim3(kBlock), 0, s, x.as<T>(),
-                       v.as<T>(), n, T(g.lam), T(g.alpha), T(g.beta), T(g.M), T(g.C),
-                       g.lam_vec ? g.lam_vec->as<T>() : nullptr,
-                       g.alpha_vec ? g.alpha_vec->as<T>() : nullptr,
-                       g.beta_vec ? g.beta_vec->as<T>() : nullptr, g.period);
-  }
+  ProfScope prof("scaled_zone", n);
+  if (x.dt == F32) LaunchScaledZone<float>(x, v, g);
+  else LaunchScaledZone<double>(x, v, g);
 }
 
 void MaxZero(const DVec& x, const DVec& v) {
   EPS_CHECK(x.n == v.n && x.dt == v.dt);
   if (x.n == 0) return;
   hipStream_t s = Runtime::Get().stream();
+  ProfScope prof("max_zero", x.n);
+  const bool vec = Aligned16(x.data()) && Aligned16(v.data());
+  const int64_t per = static_cast<int64_t>(kBlock) * 16;
+  int64_t grid = (x.n + per - 1) / per;
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
   if (x.dt == F32)
-    hipLaunchKernelGGL(MaxZeroKernel<float>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
-                       x.as<float>(), v.as<float>(), x.n);
+    hipLaunchKernelGGL(MaxZeroKernel<float>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, s,
+                       x.as<float>(), v.as<float>(), x.n, vec);
   else
-    hipLaunchKernelGGL(MaxZeroKernel<double>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
-                       x.as<double>(), v.as<double>(), x.n);
+    hipLaunchKernelGGL(MaxZeroKernel<double>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, s,
+                       x.as<double>(), v.as<double>(), x.n, vec);
 }
 
 void Norm2Shrink(const DVec& x, const DVec& v, double lam, const double* normsq) {
   EPS_CHECK(x.n == v.n && x.dt == v.dt);
   if (x.n == 0) return;
   hipStream_t s = Runtime::Get().stream();
+  const bool vec = Aligned16(x.data()) && Aligned16(v.data());
   if (x.dt == F32)
     hipLaunchKernelGGL(Norm2ShrinkKernel<float>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
-                       x.as<float>(), v.as<float>(), x.n, lam, normsq);
+                       x.as<float>(), v.as<float>(), x.n, lam, normsq, vec);
   else
     hipLaunchKernelGGL(Norm2ShrinkKernel<double>, dim3(GridFor(x.n)), dim3(kBlock), 0, s,
-                       x.as<double>(), v.as<double>(), x.n, lam, normsq);
+                       x.as<double>(), v.as<double>(), x.n, lam, normsq, vec);
 }
 
 void Tv1dSerial(const DVec& x, const DVec& v, double lam) {

@@ -269,6 +269,43 @@ DVec DenseMatrixImpl::Materialize(bool force_copy) const {
   k::MatCopy(trans_, m(), n(), scale_, data_, rows_, out);
   return out;
 }
+namespace {
+// S^-1 = V diag(1 / lambda) V^T for a symmetric S: the eigendecomposition is the SVD of the shifted
+// positive definite matrix S + cI, c > ||S||_F (singular vectors = eigenvectors, sigma = lambda + c).
+DVec SymmetricInverseByEig(const DVec& S, int64_t n) {
+  Runtime& rt = Runtime::Get();
+  rt.ResetSlots();
+  const int slot = rt.NewSlot();
+  k::SumSq(S, rt.SlotPtr(slot), false);
+  rt.FetchSlots();
+  const double fro = std::sqrt(rt.SlotValue(slot));
+  EPS_CHECK_MSG(fro > 0 && std::isfinite(fro), "dense inverse: the matrix is zero or not finite");
+  const double shift = fro * 1.0625;
+  DVec W = S.Clone();
+  k::AddDiag(W, n, n, shift, nullptr);
+  DVec V = DVec::Empty(n * n, S.dt);
+  k::JacobiSvd(W, n, n, V, 60, false, false);
+  DVec sigma = DVec::Empty(n, S.dt);
+  k::ColNorms(W, n, n, sigma, false);
+  std::vector<double> lam = sigma.ToHost();
+  const double tiny = (S.dt == F32 ? 1e-5 : 1e-12) * fro;
+  for (double& l : lam) {
+    l -= shift;
+    EPS_CHECK_MSG(std::fabs(l) > tiny, "dense inverse: the matrix is singular to working precision");
+    l = 1.0 / l;
+  }
+  DVec linv = DVec::FromHost(lam.data(), n, S.dt);
+  DVec ones = DVec::Full(n, 1.0, S.dt);
+  DVec T = V.Clone();
+  k::ColScaleByRatio(T, n, n, ones, linv);  // T = V diag(1 / lambda)
+  DVec out = DVec::Empty(n * n, S.dt);
+  k::Gemm(false, true, n, n, n, 1.0, T, n, V, n, 0.0, out, n);
+  // exactly symmetric, as the symmetric apply assumes
+  k::SymmetrizeFromLower(out, n, n);
+  return out;
+}
+}  // namespace
+
 std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Inverse() const {
   // reference dense_matrix_impl.cc:21-30: symmetric assumed, LDLT + solve(I).  Here: the
   // Schur complements of the prox KKT systems are definite, so factor sign*W by Cholesky.
@@ -292,7 +329,17 @@ std::shared_ptr<const LinearMapImpl> DenseMatrixImpl::Inverse() const {
   }
   DVec W = DVec::Empty(nn * nn, data_.dt);
   k::MatCopy(trans_, nn, nn, sign * scale_, data_, rows_, W);
-  k::SpdInverseInPlace(W, nn);
+  try {
+    k::SpdInverseInPlace(W, nn);
+  } catch (const Error&) {
+    // Not definite.  The reference's LDLT (dense_matrix_impl.cc:25-29) also inverts symmetric
+    // INDEFINITE matrices; the Schur complements of the prox KKT systems never are, so this is
+    // the rare path: through the eigendecomposition (no pivoting needed, same kernels as the
+    // symmetric matrix proxes).
+    (void)hipGetLastError();
+    k::MatCopy(trans_, nn, nn, sign * scale_, data_, rows_, W);
+    W = SymmetricInverseByEig(W, nn);
+  }
   auto result = std::make_shared<DenseMatrixImpl>(W, nn, nn, false, sign, key, true);
   if (cache && key) cache->Put(key, result);
   return result;

@@ -215,6 +215,12 @@ int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, in
 int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg);
 int eps_bench_spd_inverse_columns(int64_t n, int64_t cnt, int iters, double* ms_avg);
 
+/* Microbenchmark: average milliseconds of one launch of a standalone elementwise prox kernel on
+ * n synthetic elements of the configured dtype - kind 0 scaled-zone (NORM_1) with scalar
+ * parameters, 1 with a per-element threshold vector, 2 projection onto R+ (reference
+ * prox/scaled_zone.cc:90-101, prox/non_negative.cc:8).  Algorithmic bytes 2 n s (3 n s for kind 1). */
+int eps_bench_prox(int kind, int64_t n, int iters, double* ms_avg);
+
 /* Exact 1-D total-variation prox of v (n float64) with weight lam
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
 int eps_tv1d(const double* v, size_t n, double lam, double* x);

@@ -51,8 +51,26 @@ def inverse_columns(n, cnt, iters=2, dtype="f32"):
     print("spd_inverse_columns n=%d cnt=%d %s: %.2f ms" % (n, cnt, dtype, ms.value), flush=True)
 
 
+def prox(kind, n=10 ** 8, iters=20, dtype="f32"):
+    """standalone elementwise prox kernels (reference prox/scaled_zone.cc:90-101, non_negative.cc:8)"""
+    _solve.set_option("dtype", dtype)
+    ms = ctypes.c_double()
+    _solve._check(L.eps_bench_prox(ctypes.c_int(kind), ctypes.c_int64(n), ctypes.c_int(iters), ctypes.byref(ms)))
+    sz = 4 if dtype == "f32" else 8
+    arrays = 3 if kind == 1 else 2
+    name = ["ScaledZoneVecKernel (scalar parameters)", "ScaledZoneVecKernel (per-element threshold)",
+            "MaxZeroKernel"][kind]
+    print('{"kernel": "%s", "n": %d, "dtype": "%s", "ms": %.4f, "algorithmic_bytes": %d, "GBs": %.0f, '
+          '"frac_of_hbm_peak": %.3f}' % (name, n, dtype, ms.value, arrays * n * sz, arrays * n * sz / ms.value / 1e6,
+                                         arrays * n * sz / ms.value / 1e6 / 8000.0), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemv", "gemm", "inverse"]
+    if "prox" in what:
+        for dt in ("f32", "f64"):
+            for kind in (0, 1, 2):
+                prox(kind, dtype=dt)
     if "gemv" in what:
         gemv(0, 10000, 50000)
         gemv(1, 10000, 50000)
