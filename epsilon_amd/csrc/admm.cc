@@ -315,7 +315,7 @@ class ProxADMMSolver final : public Solver {
     f.u = state(u_, ck);
     f.y1prev = DVec::Zeros(f.n, dt);
     f.p = DVec::Zeros(f.m, dt);
-    f.grid = k::LassoFusedGrid(f.n);
+    f.grid = k::LassoFusedGrid(f.m, f.n);
     f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
     {
       Comm* comm = Runtime::Get().comm();

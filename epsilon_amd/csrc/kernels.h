@@ -58,11 +58,11 @@ struct LassoFusedArgs {
   double Bs = 0, Cs = 0, a1 = 0;    // prox-1 pre / post scaling, y1 = a1 * x1
   double lam = 0, sz_alpha = 1, sz_beta = 1, sz_M = 0;
   DVec u, x0, x1, y0, y1, y1prev;   // n each, updated in place
-  DVec tpart;                       // LassoFusedGrid(n) * m: per-workgroup partials of A v0'
+  DVec tpart;                       // LassoFusedGrid(m, n) * m: per-workgroup partials of A v0'
   unsigned* epoch = nullptr;        // optional device counter, incremented once per launch
 };
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda);
-int LassoFusedGrid(int64_t n);
+int LassoFusedGrid(int64_t m, int64_t n);
 void LassoFusedPass(const LassoFusedArgs& args);
 
 // ---- one-shot peer-write exchange (kernels_peer.hip; PeerView in comm.h) ----------------------

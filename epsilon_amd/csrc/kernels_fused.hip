@@ -183,11 +183,14 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedKernel(
 // synchronises and runs the chain; here the loads of column j+1 are issued before the dot
 // product of column j is reduced, so every workgroup keeps NR 16-byte loads per lane outstanding
 // at all times.  Same arithmetic per column, bit-identical state.
-template <int NR>
-__global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
+// BS threads own the m rows: 256 (two workgroups per CU) up to m = 10240; 512 (one workgroup of 8
+// waves per CU) up to m = 20480 (6.37 TB/s on 2e4 x 5e4).
+template <int NR, int BS>
+__global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
     int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
     FusedScalars c, float* u, float* x0, float* x1, float* y0, float* y1, float* y1prev,
     float* __restrict__ tpart, unsigned* epoch) {
+  constexpr int kBlock = BS;  // (shadows the file-level constant inside this kernel)
   __shared__ float red[2][kBlock / 64];
   // sweep counter of the peer exchange (kernels_peer.hip): the two exchange kernels that follow
   // this pass in stream order tag their granules with it
@@ -252,6 +255,8 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
     if (lane == 0) red[par][wave] = d;
     __syncthreads();
     d = ((red[par][0] + red[par][1]) + red[par][2]) + red[par][3];
+#pragma unroll
+    for (int wv2 = 4; wv2 < kBlock / 64; ++wv2) d += red[par][wv2];
     par ^= 1;
     float nx0, nx1, ny0, ny1, nu;
     const float v0n = ChainOne(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
@@ -281,34 +286,51 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedStreamKernel(
     if (row[q] < m) *reinterpret_cast<float4*>(out + row[q]) = tp[q];
 }
 
-template <int NR>
+template <int NR, int BS>
 void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, const float* w,
                  const FusedScalars& c, float* u, float* x0, float* x1, float* y0, float* y1,
                  float* y1prev, float* tpart, unsigned* epoch) {
   // default: the streaming kernel (6.0 vs 5.75 TB/s on the 1e4 x 5e4 matrix); "pair" selects the
-  // two-column form
+  // two-column form (256-thread workgroups only)
   static const char* env = std::getenv("EPSILON_HIP_FUSED_KERNEL");
-  const bool stream = !(env && env[0] == 'p');
+  const bool stream = !(env && env[0] == 'p') || BS != 256;
   if (stream) {
-    hipLaunchKernelGGL(LassoFusedStreamKernel<NR>, dim3(grid), dim3(kBlock), 0,
+    hipLaunchKernelGGL((LassoFusedStreamKernel<NR, BS>), dim3(grid), dim3(BS), 0,
                        Runtime::Get().stream(), m, n, A, lda, w, c, u, x0, x1, y0, y1, y1prev,
                        tpart, epoch);
     return;
   }
-  hipLaunchKernelGGL(LassoFusedKernel<NR>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), m,
-                     n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart, epoch);
+  if constexpr (BS == 256)
+    hipLaunchKernelGGL(LassoFusedKernel<NR>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), m,
+                       n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart, epoch);
 }
 
 }  // namespace
 
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda) {
-  return A.dt == F32 && m >= 4 && m % 4 == 0 && lda % 4 == 0 && m <= 10 * 1024 && n >= 1 &&
+  return A.dt == F32 && m >= 4 && m % 4 == 0 && lda % 4 == 0 && m <= 20 * 1024 && n >= 1 &&
          (reinterpret_cast<uintptr_t>(A.data()) % 16 == 0);
 }
 
-int LassoFusedGrid(int64_t n) {
+// Threads per workgroup of the pass: 512 when the rows do not fit 256 threads (m > 10240).
+// Measured on MI355X for m = 1e4 (EPSILON_HIP_FUSED_BLOCK=512 forces the wide form): one 512-thread
+// workgroup per CU is SLOWER than two of 256 (61.9 vs 48.4 us on a 6272-column slab, 413 vs 310 us
+// on 5e4 columns - one column in flight per CU instead of two), two per CU are equal; the halved
+// number of partial vectors does not pay either, the reduce-exchange kernel behind the pass is
+// latency-bound (11.5 us at 242 partials, 12.5 at 448).
+int LassoFusedBlock(int64_t m, int64_t n) {
+  (void)n;
+  if (m > 10 * 1024) return 512;
+  static const char* env = std::getenv("EPSILON_HIP_FUSED_BLOCK");
+  if (env && std::atoi(env) == 512 && m >= 2048) return 512;
+  return 256;
+}
+
+int LassoFusedGrid(int64_t m, int64_t n) {
   int64_t npairs = (n + 1) / 2;
-  int64_t g = 512;  // 2 workgroups per CU
+  // two 256-thread workgroups per CU; the 512-thread form with up to 5 row chunks per thread
+  // (m <= 10240) also fits twice, above that once
+  int64_t g = (LassoFusedBlock(m, n) == 512 && m > 10 * 1024) ? 256 : 512;
   static const char* env = std::getenv("EPSILON_HIP_FUSED_GRID");  // tuning knob
   if (env && std::atoi(env) > 0) g = std::atoi(env);
   if (g > npairs) g = npairs;
@@ -326,7 +348,8 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   EPS_CHECK(a.w.n == a.m && a.w.dt == F32);
   for (const DVec* v : {&a.u, &a.x0, &a.x1, &a.y0, &a.y1, &a.y1prev})
     EPS_CHECK(v->n == a.n && v->dt == F32);
-  const int grid = LassoFusedGrid(a.n);
+  const int grid = LassoFusedGrid(a.m, a.n);
+  const int block = LassoFusedBlock(a.m, a.n);
   EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == F32);
   EPS_CHECK(reinterpret_cast<uintptr_t>(a.w.data()) % 16 == 0 &&
             reinterpret_cast<uintptr_t>(a.tpart.data()) % 16 == 0);
@@ -340,16 +363,23 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   c.beta = static_cast<float>(a.sz_beta);
   c.M = static_cast<float>(a.sz_M);
   ProfScope prof("lasso_fused", a.m, a.n);
-  const int64_t need = (a.m + 1023) / 1024;
-#define EPS_FUSED_CASE(NRV)                                                                      \
-  LaunchFused<NRV>(grid, a.m, a.n, a.A.as<float>(), a.lda, a.w.as<float>(), c, a.u.as<float>(), \
-                   a.x0.as<float>(), a.x1.as<float>(), a.y0.as<float>(), a.y1.as<float>(),      \
-                   a.y1prev.as<float>(), a.tpart.as<float>(), a.epoch)
-  if (need <= 1) EPS_FUSED_CASE(1);
-  else if (need <= 2) EPS_FUSED_CASE(2);
-  else if (need <= 4) EPS_FUSED_CASE(4);
-  else if (need <= 8) EPS_FUSED_CASE(8);
-  else EPS_FUSED_CASE(10);
+  const int64_t need = (a.m + 4 * block - 1) / (4 * block);  // float4 row chunks per thread
+#define EPS_FUSED_CASE(NRV, BSV)                                                                      \
+  LaunchFused<NRV, BSV>(grid, a.m, a.n, a.A.as<float>(), a.lda, a.w.as<float>(), c, a.u.as<float>(), \
+                        a.x0.as<float>(), a.x1.as<float>(), a.y0.as<float>(), a.y1.as<float>(),      \
+                        a.y1prev.as<float>(), a.tpart.as<float>(), a.epoch)
+  if (block == 256) {
+    if (need <= 1) EPS_FUSED_CASE(1, 256);
+    else if (need <= 2) EPS_FUSED_CASE(2, 256);
+    else if (need <= 4) EPS_FUSED_CASE(4, 256);
+    else if (need <= 8) EPS_FUSED_CASE(8, 256);
+    else EPS_FUSED_CASE(10, 256);
+  } else {
+    if (need <= 2) EPS_FUSED_CASE(2, 512);
+    else if (need <= 5) EPS_FUSED_CASE(5, 512);
+    else if (need <= 8) EPS_FUSED_CASE(8, 512);
+    else EPS_FUSED_CASE(10, 512);
+  }
 #undef EPS_FUSED_CASE
 }
 

@@ -193,26 +193,41 @@ __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
   }
   if ((t & 63) < kRQ) part[wave][rq] = s;
   __syncthreads();
-  if (t >= kRQ || r0 >= rows) return;
-  const unsigned tag = 2u * (*pv.epoch) + 1u;
-  const float4 a = part[0][rq], b = part[1][rq], c = part[2][rq], d = part[3][rq];
-  const float mine[4] = {alpha * (((a.x + b.x) + c.x) + d.x), alpha * (((a.y + b.y) + c.y) + d.y),
-                         alpha * (((a.z + b.z) + c.z) + d.z), alpha * (((a.w + b.w) + c.w) + d.w)};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) PushAll(pv, 0, r0 + e, tag, mine[e]);
-  float out[4];
-  float val[4][PeerView::kMaxPeers];
-  PollAll<4>(pv, 0, r0, tag, val, 1u);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float acc = val[e][0];
-#pragma unroll
-    for (int q = 1; q < PeerView::kMaxPeers; ++q)
-      if (q < pv.G) acc += val[e][q];
-    if (add) acc += add[r0 + e];
-    out[e] = acc;
+  // The exchange is spread over the whole workgroup: thread (row, q) = (t & 31, t >> 5) pushes ONE
+  // granule to peer q and polls ONE granule of source q - one store and one load per lane and
+  // round instead of 32 of each on 8 lanes (the kernel is latency-bound, not bandwidth-bound).
+  static_assert(kRQ * 4 * PeerView::kMaxPeers == kBlock, "one (row, peer) pair per thread");
+  __shared__ float mine_s[kRQ * 4];
+  __shared__ float got[PeerView::kMaxPeers][kRQ * 4];
+  const long long rbase = static_cast<long long>(blockIdx.x) * kRQ * 4;
+  if (t < kRQ * 4) {
+    const float4 a = part[0][t >> 2], b = part[1][t >> 2], c = part[2][t >> 2], d = part[3][t >> 2];
+    const int e = t & 3;
+    const float av = e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w;
+    const float bv = e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w;
+    const float cv = e == 0 ? c.x : e == 1 ? c.y : e == 2 ? c.z : c.w;
+    const float dv = e == 0 ? d.x : e == 1 ? d.y : e == 2 ? d.z : d.w;
+    mine_s[t] = alpha * (((av + bv) + cv) + dv);
   }
-  *reinterpret_cast<float4*>(y + r0) = make_float4(out[0], out[1], out[2], out[3]);
+  __syncthreads();
+  const unsigned tag = 2u * (*pv.epoch) + 1u;
+  {
+    const int row = t & (kRQ * 4 - 1), q = t >> 5;  // kRQ * 4 == 32
+    const long long r = rbase + row;
+    if (q < pv.G && r < rows) {
+      PushGranule(Slot(pv, q, 0, pv.rehearse ? q : pv.rank, r), Granule(tag, mine_s[row]));
+      float v;
+      PollOne(pv, 0, q, r, tag, &v, 1u);
+      got[q][row] = v;
+    }
+  }
+  __syncthreads();
+  if (t < kRQ * 4 && rbase + t < rows) {
+    float acc = got[0][t];
+    for (int q = 1; q < pv.G; ++q) acc += got[q][t];
+    if (add) acc += add[rbase + t];
+    y[rbase + t] = acc;
+  }
 }
 
 // w[q*slab + j] for all q: this rank computes j < slab of its own slab
@@ -278,13 +293,16 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
       if (lane == 0) red[wave][c] = v;
     }
     __syncthreads();
-    if (threadIdx.x < CP && j0 + threadIdx.x < slab) {
-      const int c = threadIdx.x;
-      const float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-      PushAll(pv, 1, j0 + c, tag, scale * t);
-      // the own slab goes straight into w: no workgroup of this grid ever waits for another
-      // workgroup of the same grid, only for other GPUs
-      if (!pv.rehearse) wpad[static_cast<long long>(pv.rank) * slab + j0 + c] = scale * t;
+    // thread (c, q) pushes column c's result to peer q: one store per lane
+    if (threadIdx.x < CP * PeerView::kMaxPeers) {
+      const int c = threadIdx.x % CP, q = threadIdx.x / CP;
+      if (j0 + c < slab && q < pv.G) {
+        const float t = scale * (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+        PushGranule(Slot(pv, q, 1, pv.rehearse ? q : pv.rank, j0 + c), Granule(tag, t));
+        // the own slab goes straight into w: no workgroup of this grid ever waits for another
+        // workgroup of the same grid, only for other GPUs
+        if (q == 0 && !pv.rehearse) wpad[static_cast<long long>(pv.rank) * slab + j0 + c] = t;
+      }
     }
     __syncthreads();
   }

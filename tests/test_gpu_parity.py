@@ -604,7 +604,8 @@ def test_rccl_backend_single_rank(solve_mod):
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (4100, 4301), (8, 21), (1500, 701)])
+@pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (4100, 4301), (8, 21), (1500, 701),
+                                   (10244, 10260)])   # past the 10240 rows that 256 threads hold
 @pytest.mark.parametrize("kind", ["lasso", "deadzone"])
 def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
     """The one-pass fused sweep (kernels_fused.hip) against the unfused operator path (same
