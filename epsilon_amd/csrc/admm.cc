@@ -106,26 +106,59 @@ int Solver::Run(int max_sweeps) {
   int done = 0;
   const int epoch = params_.epoch_iterations > 0 ? params_.epoch_iterations : 1;
   const int log_every = params_.log_iterations > 0 ? params_.log_iterations : 1;
-  while (!finished_ && iter_ < params_.max_iterations && (max_sweeps < 0 || done < max_sweeps)) {
-    // the sweeps up to and including the next one that is followed by a host decision (residual
-    // check; log line when verbose) are enqueued as one batch
+  // the sweeps from iteration `it` up to and including the next one that is followed by a host
+  // decision (residual check; log line when verbose), clipped to the limits; 0 = none left
+  auto batch_size = [&](int it, int done_so_far) {
+    if (it >= params_.max_iterations || (max_sweeps >= 0 && done_so_far >= max_sweeps)) return 0;
     int batch = 1;
-    while ((iter_ + batch - 1) % epoch != 0 &&
-           !(params_.verbose && (iter_ + batch - 1) % log_every == 0))
+    while ((it + batch - 1) % epoch != 0 && !(params_.verbose && (it + batch - 1) % log_every == 0))
       ++batch;
-    if (batch > params_.max_iterations - iter_) batch = params_.max_iterations - iter_;
-    if (max_sweeps >= 0 && batch > max_sweeps - done) batch = max_sweeps - done;
-    SweepBatch(batch);
+    if (batch > params_.max_iterations - it) batch = params_.max_iterations - it;
+    if (max_sweeps >= 0 && batch > max_sweeps - done_so_far) batch = max_sweeps - done_so_far;
+    return batch;
+  };
+  int speculated = 0;  // sweeps of the NEXT batch already enqueued behind a pending check
+  // A speculative batch is wasted work when its check says OPTIMAL, so none is started once the
+  // last check was within a factor 4 of both tolerances (the residuals fall geometrically, the
+  // next check is then likely the last): the steady state gets the overlap, the time to OPTIMAL
+  // does not pay for it.
+  auto far_from_optimal = [&] {
+    if (status_.epsilon_primal <= 0 || status_.epsilon_dual <= 0) return true;  // no check yet
+    return status_.r_norm > 4 * status_.epsilon_primal || status_.s_norm > 4 * status_.epsilon_dual;
+  };
+  while (!finished_ && iter_ < params_.max_iterations && (max_sweeps < 0 || done < max_sweeps)) {
+    int batch = speculated;
+    if (batch == 0) {
+      batch = batch_size(iter_, done);
+      SweepBatch(batch);
+    }
+    speculated = 0;
     done += batch;
     iter_ += batch - 1;  // index of the last sweep of the batch
-    if (iter_ % params_.epoch_iterations == 0) {
-      ComputeResiduals();
-      if (status_.state == pb::SolverStatus::OPTIMAL) {
-        finished_ = true;
-        break;
+    if (iter_ % epoch == 0) {
+      const int next = (PipelinedChecks() && (params_.ignore_stopping_criteria || far_from_optimal()))
+                           ? batch_size(iter_ + 1, done)
+                           : 0;
+      if (next > 0) {
+        BeginResiduals();
+        SaveSnapshot();
+        SweepBatch(next);  // runs on the device while the host waits for the check's scalars
+        speculated = next;
+        EndResiduals();
+        if (status_.state == pb::SolverStatus::OPTIMAL) {
+          RestoreSnapshot();  // the speculative sweeps are discarded (and were never counted)
+          finished_ = true;
+          break;
+        }
+      } else {
+        ComputeResiduals();
+        if (status_.state == pb::SolverStatus::OPTIMAL) {
+          finished_ = true;
+          break;
+        }
       }
     }
-    if (iter_ % params_.log_iterations == 0) LogStatus();
+    if (iter_ % log_every == 0) LogStatus();
     ++iter_;
   }
   if (!finished_ && iter_ == params_.max_iterations) {
@@ -303,8 +336,15 @@ class ProxADMMSolver final : public Solver {
     if (!k::LassoFusedSupported(f.m, f.n, L.data(), L.rows())) return;
     if (f.ls.rhs_arg.n != 0 && f.ls.rhs_arg.n != f.m) return;
     const DType dt = F32;
+    // the six state vectors are slices of ONE buffer, so that a residual check can snapshot the
+    // iterates with a single copy (pipelined checks, Solver::Run)
+    const int64_t npad = (f.n + 63) / 64 * 64;
+    f.state_all = DVec::Zeros(6 * npad, dt);
+    f.snapshot = DVec::Empty(6 * npad, dt);
+    f.norm_work = DVec::Zeros(64 * 5 + 1, F64);
+    int next_slice = 0;
     auto state = [&](const BlockVector& src, const std::string& key) {
-      DVec v = DVec::Zeros(f.n, dt);
+      DVec v = f.state_all.Slice(static_cast<int64_t>(next_slice++) * npad, f.n);
       if (src.has_key(key)) k::Copy(v, src(key));
       return v;
     };
@@ -313,7 +353,7 @@ class ProxADMMSolver final : public Solver {
     f.y0 = state(y_[0], ck);
     f.y1 = state(y_[1], ck);
     f.u = state(u_, ck);
-    f.y1prev = DVec::Zeros(f.n, dt);
+    f.y1prev = state(BlockVector(), ck);
     f.p = DVec::Zeros(f.m, dt);
     f.grid = k::LassoFusedGrid(f.m, f.n);
     f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
@@ -544,7 +584,57 @@ class ProxADMMSolver final : public Solver {
     }
   }
 
+  // ---- residual check of the fused structure: one launch, splittable for pipelining ------------
+  // With A_ = [a0 I, a1 I] (a0 = 1), b_ empty and N = 2 the quantities of :178-217 are
+  //   ||A x_i|| = ||y_i||,  r = ||y0 + y1||,  s = rho ||A_0^T (y1 - y1_prev)|| = rho ||y1 - y1_prev||,
+  //   ||A^T u||^2 = (a0^2 + a1^2) ||u||^2.
+  bool PipelinedChecks() const override {
+    static const bool off = [] {
+      const char* e = std::getenv("EPSILON_HIP_PIPELINE_CHECKS");
+      return e && e[0] == '0';
+    }();
+    const ShardSpec& sh = ShardSpec::Get();
+    return fused_ && !off && !(sh.active() && sh.consensus_terms());
+  }
+  void BeginResiduals() override {
+    Runtime& rt = Runtime::Get();
+    FusedState& f = fs_;
+    rt.ResetSlots();
+    norm_slot_ = rt.NewSlot();
+    for (int k = 1; k < 5; ++k) rt.NewSlot();
+    const ShardSpec& sh = ShardSpec::Get();
+    const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
+    k::LassoFusedNorms(f.u, f.y0, f.y1, f.y1prev,
+                       sharded ? rt.ShardSlotPtr(norm_slot_) : rt.SlotPtr(norm_slot_), f.norm_work);
+    rt.FetchSlotsAsync();
+  }
+  void EndResiduals() override {
+    Runtime& rt = Runtime::Get();
+    rt.WaitSlots();
+    if (rt.peer()) rt.peer()->CheckError();
+    const double ny0 = rt.SlotValue(norm_slot_), ny1 = rt.SlotValue(norm_slot_ + 1),
+                 nr = rt.SlotValue(norm_slot_ + 2), ns = rt.SlotValue(norm_slot_ + 3),
+                 nu = rt.SlotValue(norm_slot_ + 4);
+    const double rho = params_.rho;
+    const double max_norm = std::fmax(std::sqrt(ny0), std::sqrt(ny1));
+    FinishResiduals(std::sqrt(nr), rho * std::sqrt(ns),
+                    params_.abs_tol * std::sqrt(static_cast<double>(m_)) + params_.rel_tol * max_norm,
+                    params_.abs_tol * std::sqrt(static_cast<double>(n_)) +
+                        params_.rel_tol * rho * std::sqrt((1.0 + fs_.a1 * fs_.a1) * nu));
+  }
+  void SaveSnapshot() override { k::Copy(fs_.snapshot, fs_.state_all); }
+  void RestoreSnapshot() override {
+    Runtime::Get().Sync();  // let the discarded sweeps drain
+    if (Runtime::Get().peer()) Runtime::Get().peer()->CheckError();
+    k::Copy(fs_.state_all, fs_.snapshot);
+  }
+
   void ComputeResiduals() override {  // :178-217
+    if (fused_) {
+      BeginResiduals();
+      EndResiduals();
+      return;
+    }
     Runtime& rt = Runtime::Get();
     rt.ResetSlots();
     const int s_b = b_.NormSqAsync();
@@ -609,9 +699,12 @@ class ProxADMMSolver final : public Solver {
     bool peer_slab = false;  // ... and the inverse is applied by row slabs
     DVec u, x0, x1, y0, y1, y1prev, w, p, tpart, wpad, wslice;
     DVec symv_work;  // fixed workspace of the symmetric inverse apply (empty: not that form)
+    DVec state_all, snapshot;  // u, x0, x1, y0, y1, y1prev in one buffer; its copy at a check
+    DVec norm_work;            // partials + ticket of the one-launch residual norms
   };
   bool fused_ = false;
   FusedState fs_;
+  int norm_slot_ = 0;
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;
   int graph_len_ = 0;

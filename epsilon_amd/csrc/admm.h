@@ -53,6 +53,17 @@ class Solver {
     for (int i = 0; i < count; ++i) Sweep();
   }
   virtual void ComputeResiduals() = 0;
+  // Pipelined residual checks: a driver that can (a) split a check into device work that is only
+  // ENQUEUED (BeginResiduals) and the host decision (EndResiduals), and (b) save / restore its
+  // iterates, lets Run() enqueue the next batch of sweeps before it waits for the check's scalars,
+  // so the host round trip (and, sharded, the all-reduce of the scalars) hides behind useful work.
+  // If the check says OPTIMAL the iterates of the check are restored: results are exactly those
+  // of the unpipelined loop.
+  virtual bool PipelinedChecks() const { return false; }
+  virtual void BeginResiduals() {}
+  virtual void EndResiduals() {}
+  virtual void SaveSnapshot() {}
+  virtual void RestoreSnapshot() {}
   void LogStatus();
   void FinishResiduals(double r2, double s2, double eps_pri, double eps_dual);
 

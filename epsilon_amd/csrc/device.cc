@@ -106,6 +106,16 @@ void Runtime::ResetSlots() {
 }
 
 void Runtime::FetchSlots() {
+  FetchSlotsAsync();
+  WaitSlots();
+}
+
+void Runtime::WaitSlots() {
+  if (slots_event_) EPS_HIP(hipEventSynchronize(slots_event_));
+  else EPS_HIP(hipStreamSynchronize(stream_));
+}
+
+void Runtime::FetchSlotsAsync() {
   if (slots_used_ > 0) {
     const bool sharded = ShardSpec::Get().active();
     // consensus form: this rank's own share of the sharded half is kept too (per-rank terms)
@@ -119,7 +129,8 @@ void Runtime::FetchSlots() {
       EPS_HIP(hipMemcpyAsync(slots_host_ + kMaxSlots, slots_dev_ + kMaxSlots,
                              slots_used_ * sizeof(double), hipMemcpyDeviceToHost, stream_));
   }
-  EPS_HIP(hipStreamSynchronize(stream_));
+  if (!slots_event_) EPS_HIP(hipEventCreateWithFlags(&slots_event_, hipEventDisableTiming));
+  EPS_HIP(hipEventRecord(slots_event_, stream_));
 }
 
 void Runtime::Sync() { EPS_HIP(hipStreamSynchronize(stream_)); }

@@ -57,6 +57,11 @@ class Runtime {
   double* ShardSlotPtr(int i) { return slots_dev_ + kMaxSlots + i; }
   void ResetSlots();  // rewinds and zeroes (on the stream)
   void FetchSlots();
+  // The same in two halves: FetchSlotsAsync enqueues the (all-reduce and) copy and records an
+  // event, WaitSlots blocks the host until that copy has landed - work enqueued in between runs
+  // on the device while the host waits (pipelined residual checks, admm.cc).
+  void FetchSlotsAsync();
+  void WaitSlots();
   double SlotValue(int i) const { return slots_host_[i] + slots_host_[kMaxSlots + i]; }
   // before the sum over ranks (valid when ShardSpec::consensus_terms() is set)
   double SlotLocalValue(int i) const { return slots_host_[i] + slots_host_[2 * kMaxSlots + i]; }
@@ -98,6 +103,7 @@ class Runtime {
   double* slots_dev_ = nullptr;
   double* slots_host_ = nullptr;
   int slots_used_ = 0;
+  hipEvent_t slots_event_ = nullptr;
   Comm* comm_ = nullptr;
   PeerExchange* peer_ = nullptr;
   bool capturing_ = false;

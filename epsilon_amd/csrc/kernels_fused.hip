@@ -307,6 +307,90 @@ void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, co
 
 }  // namespace
 
+namespace {
+
+// The five sums of squares of a residual check of the fused structure in ONE launch (the generic
+// path takes ~10 launches and three temporaries for them): ||y0||^2, ||y1||^2, ||y0 + y1||^2,
+// ||y1 - y1prev||^2, ||u||^2, accumulated in double.  Every workgroup reduces a contiguous part
+// and publishes five partials; the workgroup whose ticket comes last adds the partials in
+// workgroup order - deterministic, one launch.  (Hand-off: sc1 stores, every storing wave drained,
+// one agent-scope ticket per workgroup; the last arriver reads with sc1 loads - MI355X_MICROARCH.md,
+// Valid forms, first row.)
+constexpr int kNormBlocks = 64;
+
+__device__ inline double WaveSumD(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void LassoFusedNormsKernel(
+    int64_t n, const float* __restrict__ u, const float* __restrict__ y0, const float* __restrict__ y1,
+    const float* __restrict__ y1prev, double* partial, unsigned* ticket, double* out) {
+  __shared__ double red[kBlock / 64][5];
+  __shared__ bool last;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per;
+  int64_t hi = lo + per;
+  if (hi > n) hi = n;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) {
+    const double a = y0[i], b = y1[i], c = y1prev[i], d = u[i];
+    s[0] += a * a;
+    s[1] += b * b;
+    s[2] += (a + b) * (a + b);
+    s[3] += (b - c) * (b - c);
+    s[4] += d * d;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double t = WaveSumD(s[k]);
+    if (lane == 0) red[wave][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const int k = threadIdx.x;
+    const double t = ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k];
+    __hip_atomic_store(partial + blockIdx.x * 5 + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = prev == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x < 5) {
+    const int k = threadIdx.x;
+    double t = 0;
+    for (unsigned b = 0; b < gridDim.x; ++b)
+      t += __hip_atomic_load(partial + b * 5 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[k] = t;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& y1prev, double* out5,
+                     const DVec& work) {
+  const int64_t n = u.n;
+  EPS_CHECK(u.dt == F32 && y0.n == n && y1.n == n && y1prev.n == n);
+  EPS_CHECK(work.dt == F64 && work.n >= kNormBlocks * 5 + 1);
+  int64_t grid = (n + 4 * kBlock - 1) / (4 * kBlock);
+  if (grid > kNormBlocks) grid = kNormBlocks;
+  if (grid < 1) grid = 1;
+  double* partial = work.as<double>();
+  unsigned* ticket = reinterpret_cast<unsigned*>(partial + kNormBlocks * 5);  // zero between launches
+  ProfScope prof("lasso_fused_norms", n);
+  hipLaunchKernelGGL(LassoFusedNormsKernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                     Runtime::Get().stream(), n, u.as<float>(), y0.as<float>(), y1.as<float>(),
+                     y1prev.as<float>(), partial, ticket, out5);
+  EPS_HIP(hipGetLastError());
+}
+
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda) {
   return A.dt == F32 && m >= 4 && m % 4 == 0 && lda % 4 == 0 && m <= 20 * 1024 && n >= 1 &&
          (reinterpret_cast<uintptr_t>(A.data()) % 16 == 0);

@@ -569,6 +569,77 @@ void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, do
   EPS_HIP(hipGetLastError());
 }
 
+namespace {
+// The same reduction with 16-byte loads for the partial vectors of the fused sweep (hundreds of
+// vectors of m floats, 20 MB at config 2): a workgroup owns 32 rows, thread (rq, pl) = (t & 7,
+// t >> 3) sums the float4 of rows 4 rq .. 4 rq + 3 over the partials k = pl, pl + 32, ... (all of a
+// thread's loads independent), then the 32 part lanes are combined by three shuffle steps inside a
+// wave and the 4 waves in order - a fixed summation order.
+constexpr int kRQ4 = 8, kPL4 = kBlock / kRQ4;
+
+__global__ __launch_bounds__(kBlock) void ReducePartials4Kernel(int64_t rows, int nparts,
+                                                                const float* __restrict__ partial,
+                                                                float alpha, float beta, float* y,
+                                                                const float* __restrict__ add) {
+  __shared__ float4 part[kBlock / 64][kRQ4];
+  const int t = threadIdx.x, rq = t & (kRQ4 - 1), pl = t >> 3, wave = t >> 6;
+  const int64_t r0 = (static_cast<int64_t>(blockIdx.x) * kRQ4 + rq) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r0 < rows) {
+    const float* p = partial + r0;
+    int k = pl;
+    for (; k + 7 * kPL4 < nparts; k += 8 * kPL4) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float4*>(p + static_cast<int64_t>(k + u * kPL4) * rows);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s.x += v[u].x;
+        s.y += v[u].y;
+        s.z += v[u].z;
+        s.w += v[u].w;
+      }
+    }
+    for (; k < nparts; k += kPL4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + static_cast<int64_t>(k) * rows);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 8; off >>= 1) {
+    s.x += __shfl_down(s.x, off, 64);
+    s.y += __shfl_down(s.y, off, 64);
+    s.z += __shfl_down(s.z, off, 64);
+    s.w += __shfl_down(s.w, off, 64);
+  }
+  if ((t & 63) < kRQ4) part[wave][rq] = s;
+  __syncthreads();
+  if (t >= kRQ4 || r0 >= rows) return;
+  const float4 a = part[0][rq], b = part[1][rq], c = part[2][rq], d = part[3][rq];
+  float o[4] = {alpha * (((a.x + b.x) + c.x) + d.x), alpha * (((a.y + b.y) + c.y) + d.y),
+                alpha * (((a.z + b.z) + c.z) + d.z), alpha * (((a.w + b.w) + c.w) + d.w)};
+  if (beta != 0.f) {
+    const float4 yo = *reinterpret_cast<const float4*>(y + r0);
+    o[0] += beta * yo.x;
+    o[1] += beta * yo.y;
+    o[2] += beta * yo.z;
+    o[3] += beta * yo.w;
+  }
+  if (add) {
+    const float4 ad = *reinterpret_cast<const float4*>(add + r0);
+    o[0] += ad.x;
+    o[1] += ad.y;
+    o[2] += ad.z;
+    o[3] += ad.w;
+  }
+  *reinterpret_cast<float4*>(y + r0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+}  // namespace
+
 void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha, double beta,
                     const DVec& y, const DVec* add) {
   EPS_CHECK(partial.dt == y.dt && y.n == rows && partial.n >= static_cast<int64_t>(nparts) * rows);
@@ -576,6 +647,14 @@ void ReducePartials(int64_t rows, int nparts, const DVec& partial, double alpha,
   if (rows == 0) return;
   hipStream_t s = Runtime::Get().stream();
   ProfScope prof("reduce_partials", rows, nparts);
+  auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+  if (y.dt == F32 && rows % 4 == 0 && nparts >= 64 && al16(partial.data()) && al16(y.data()) &&
+      (!add || al16(add->data()))) {
+    hipLaunchKernelGGL(ReducePartials4Kernel, dim3(static_cast<unsigned>((rows / 4 + kRQ4 - 1) / kRQ4)),
+                       dim3(kBlock), 0, s, rows, nparts, partial.as<float>(), static_cast<float>(alpha),
+                       static_cast<float>(beta), y.as<float>(), add ? add->as<float>() : nullptr);
+    return;
+  }
   const unsigned grid = static_cast<unsigned>((rows + 63) / 64);
   if (y.dt == F32)
     hipLaunchKernelGGL(GemvNReduceKernel<float>, dim3(grid), dim3(kBlock), 0, s, rows, nparts,
