@@ -250,6 +250,10 @@ def comm_enable_peer(slot_floats=0, rehearse_ranks=0):
     return bool(on.value), ("" if on.value else lib().eps_last_error().decode("utf-8", "replace"))
 
 
+def comm_disable_peer():
+    _check(lib().eps_comm_disable_peer())
+
+
 def comm_shutdown():
     _check(lib().eps_comm_shutdown())
     del _comm_keep[:]

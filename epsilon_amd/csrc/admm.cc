@@ -601,17 +601,24 @@ class ProxADMMSolver final : public Solver {
     FusedState& f = fs_;
     rt.ResetSlots();
     norm_slot_ = rt.NewSlot();
-    for (int k = 1; k < 5; ++k) rt.NewSlot();
+    for (int k = 1; k < 6; ++k) rt.NewSlot();
     const ShardSpec& sh = ShardSpec::Get();
     const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
     k::LassoFusedNorms(f.u, f.y0, f.y1, f.y1prev,
-                       sharded ? rt.ShardSlotPtr(norm_slot_) : rt.SlotPtr(norm_slot_), f.norm_work);
+                       sharded ? rt.ShardSlotPtr(norm_slot_) : rt.SlotPtr(norm_slot_), f.norm_work,
+                       f.use_peer ? rt.peer()->device_error_word() : nullptr);
     rt.FetchSlotsAsync();
   }
   void EndResiduals() override {
     Runtime& rt = Runtime::Get();
     rt.WaitSlots();
-    if (rt.peer()) rt.peer()->CheckError();
+    // a timed-out exchange on ANY rank shows in the all-reduced sixth value: every rank raises at
+    // the same check, none is left waiting in a collective the others never enter
+    if (rt.SlotValue(norm_slot_ + 5) > 0) {
+      rt.Sync();
+      if (rt.peer()) rt.peer()->ClearError();
+      EPS_FATAL("peer exchange: a poll timed out on at least one rank (a peer did not deliver its part)");
+    }
     const double ny0 = rt.SlotValue(norm_slot_), ny1 = rt.SlotValue(norm_slot_ + 1),
                  nr = rt.SlotValue(norm_slot_ + 2), ns = rt.SlotValue(norm_slot_ + 3),
                  nu = rt.SlotValue(norm_slot_ + 4);

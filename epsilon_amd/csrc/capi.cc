@@ -352,6 +352,15 @@ int eps_comm_enable_peer(size_t slot_floats, int rehearse_ranks, int* enabled) {
   });
 }
 
+int eps_comm_disable_peer(void) {
+  return Guard([&] {
+    Runtime& rt = Runtime::Get();
+    rt.Sync();
+    delete rt.peer();
+    rt.set_peer(nullptr);
+  });
+}
+
 int eps_comm_shutdown(void) {
   return Guard([&] {
     Runtime& rt = Runtime::Get();

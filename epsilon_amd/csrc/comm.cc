@@ -311,6 +311,11 @@ PeerExchange::~PeerExchange() {
   if (err_host_) (void)hipHostFree(err_host_);
 }
 
+void PeerExchange::ClearError() {
+  if (err_host_) *err_host_ = 0;
+  (void)hipMemset(view_.epoch + 16, 0, sizeof(unsigned));
+}
+
 void PeerExchange::CheckError() {
   if (err_host_ && *err_host_ != 0) {
     const unsigned code = *err_host_;

@@ -84,6 +84,10 @@ class PeerExchange {
   void SelfTest();
   // Throws if a kernel reported a timed-out poll since the last call (stream must be drained).
   void CheckError();
+  // The device-side copy of the error word (read by the residual-norm kernel, so that a failure
+  // on any rank reaches every rank through the check's all-reduce); ClearError resets both.
+  const unsigned* device_error_word() const { return view_.epoch + 16; }
+  void ClearError();
 
  private:
   PeerExchange() {}

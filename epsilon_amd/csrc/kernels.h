@@ -64,10 +64,11 @@ struct LassoFusedArgs {
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda);
 int LassoFusedGrid(int64_t m, int64_t n);
 void LassoFusedPass(const LassoFusedArgs& args);
-// out5 = {||y0||^2, ||y1||^2, ||y0 + y1||^2, ||y1 - y1prev||^2, ||u||^2} (device doubles), one
-// launch; `work`: 64 * 5 + 1 doubles, zero-initialised once (the last double is a ticket counter).
-void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& y1prev, double* out5,
-                     const DVec& work);
+// out6 = {||y0||^2, ||y1||^2, ||y0 + y1||^2, ||y1 - y1prev||^2, ||u||^2, peer_err ? 1 : 0} (device
+// doubles), one launch; `work`: 64 * 5 + 1 doubles, zero-initialised once (the last double is a
+// ticket counter); `peer_err` (optional): the device-side error word of the peer exchange.
+void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& y1prev, double* out6,
+                     const DVec& work, const unsigned* peer_err = nullptr);
 
 // ---- one-shot peer-write exchange (kernels_peer.hip; PeerView in comm.h) ----------------------
 void PeerBumpEpoch(const PeerView& pv);

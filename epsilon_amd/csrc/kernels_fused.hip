@@ -326,7 +326,8 @@ __device__ inline double WaveSumD(double v) {
 
 __global__ __launch_bounds__(kBlock) void LassoFusedNormsKernel(
     int64_t n, const float* __restrict__ u, const float* __restrict__ y0, const float* __restrict__ y1,
-    const float* __restrict__ y1prev, double* partial, unsigned* ticket, double* out) {
+    const float* __restrict__ y1prev, double* partial, unsigned* ticket, double* out,
+    const unsigned* peer_err) {
   __shared__ double red[kBlock / 64][5];
   __shared__ bool last;
   const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -369,13 +370,18 @@ __global__ __launch_bounds__(kBlock) void LassoFusedNormsKernel(
       t += __hip_atomic_load(partial + b * 5 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[k] = t;
   }
+  // sixth value: "an exchange kernel of this rank timed out" - it travels with the norms through
+  // the all-reduce of the check, so every rank learns of a failure on ANY rank at the same check
+  if (threadIdx.x == 5)
+    out[5] = (peer_err != nullptr &&
+              __hip_atomic_load(peer_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1.0 : 0.0;
   if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
 
-void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& y1prev, double* out5,
-                     const DVec& work) {
+void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& y1prev, double* out6,
+                     const DVec& work, const unsigned* peer_err) {
   const int64_t n = u.n;
   EPS_CHECK(u.dt == F32 && y0.n == n && y1.n == n && y1prev.n == n);
   EPS_CHECK(work.dt == F64 && work.n >= kNormBlocks * 5 + 1);
@@ -387,7 +393,7 @@ void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& 
   ProfScope prof("lasso_fused_norms", n);
   hipLaunchKernelGGL(LassoFusedNormsKernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
                      Runtime::Get().stream(), n, u.as<float>(), y0.as<float>(), y1.as<float>(),
-                     y1prev.as<float>(), partial, ticket, out5);
+                     y1prev.as<float>(), partial, ticket, out6, peer_err);
   EPS_HIP(hipGetLastError());
 }
 

@@ -528,8 +528,17 @@ template <class T> struct BoundOp {
     const int64_t c0 = (tile * kBlock + chunk) * kItems;
     ctx.bytes = *reinterpret_cast<const uint4*>(s.st + c0);
     const unsigned w[4] = {ctx.bytes.x, ctx.bytes.y, ctx.bytes.z, ctx.bytes.w};
-    const int bl = c0 > 0 ? s.st[c0 - 1] : 0;
-    const int br = c0 + kItems < s.n ? s.st[c0 + kItems] : 0;
+    // The bytes left and right of the chunk sit in the neighbouring lanes' registers (the scan runs
+    // backwards: the chunk before this one belongs to lane + 1, the one after it to lane - 1);
+    // only the lanes at a wave's edge read them from memory (two scalar byte loads per thread made
+    // this kernel run at 1.4 TB/s).
+    const int lane = threadIdx.x & 63;
+    const unsigned up = __shfl_down(ctx.bytes.w, 1, 64), dn = __shfl_up(ctx.bytes.x, 1, 64);
+    int bl = static_cast<int>(up >> 24), br = static_cast<int>(dn & 0xff);
+    if (lane == 63) bl = c0 > 0 ? s.st[c0 - 1] : 0;
+    if (lane == 0) br = c0 + kItems < s.n ? s.st[c0 + kItems] : 0;
+    if (c0 == 0) bl = 0;
+    if (c0 + kItems >= s.n) br = 0;
     ctx.new_head = ctx.new_end = ctx.cut_left = ctx.cut_right = 0;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {

@@ -158,6 +158,8 @@ int eps_comm_warmup(size_t count);
  * changes (RCCL per sweep) and eps_last_error() says why.  The reference has no counterpart
  * (it has no distributed mode). */
 int eps_comm_enable_peer(size_t slot_floats, int rehearse_ranks, int* enabled);
+/* Drop the window again (every rank, or none): later solves use the communicator's collectives. */
+int eps_comm_disable_peer(void);
 int eps_comm_shutdown(void);
 /* Replace the set of sharded block keys (variable ids and "constraint:<i>" rows). */
 int eps_shard_keys(const char* const* keys, size_t nkeys);
