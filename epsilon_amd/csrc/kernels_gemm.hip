@@ -11,6 +11,7 @@
 //    The accumulator is produced transposed (MFMA "A" operand <- B tile) so that a register's
 //    32 lanes hit 32 consecutive rows of column-major C: 128-byte coalesced stores.
 //  * GemmGeneric<T>: 64x64 LDS-tiled VALU kernel for f64 and for small shapes.
+//  * GemmMfmaF64: the f32 tile on v_mfma_f64_16x16x4_f64, opt-in (slower than the VALU kernel today).
 //
 // `lower_only` skips tiles strictly above the diagonal (SYRK-style, half the flops).
 #include <hip/hip_runtime.h>
@@ -442,15 +443,121 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
   }
 }
 
-int GemmMode() {  // 0 auto, 1 generic, 2 mfma, 3 mfma without the pipelined kernel
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = std::getenv("EPSILON_HIP_GEMM");
-    mode = 0;
-    if (e && std::strcmp(e, "generic") == 0) mode = 1;
-    if (e && std::strcmp(e, "mfma") == 0) mode = 2;
-    if (e && std::strcmp(e, "mfma_simple") == 0) mode = 3;
+// ------------------------------------------------------------------------------------------
+// f64 MFMA kernel (the fp64 mode's GEMMs: the reference arithmetic is fp64, linear/linear_map.h:35)
+//   v_mfma_f64_16x16x4_f64: A / B one f64 per lane (A[l&15][k = l>>4], B[k = l>>4][l&15]),
+//   C / D four f64 per lane with  col = l & 15, row = (l >> 4) + 4 * reg  (NOT the f32 map).
+// Same geometry as the f32 kernel: 128 x 128 tile, 4 waves as 2 x 2, each wave 4 x 4 blocks of
+// 16 x 16; the MFMA "A" operand takes the B tile, so a register's lanes 0..15 hit 16 consecutive
+// rows of column-major C (128-byte stores).  k slabs of 16, staged through LDS as [k][row].
+// ------------------------------------------------------------------------------------------
+constexpr int DK = 16;           // k slab
+constexpr int DLD = MT + 2;      // LDS row stride (doubles)
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+__device__ inline void StageTileF64(double (*S)[DLD], const double* __restrict__ X, int64_t ld,
+                                    bool contiguous_r, int64_t r0, int64_t k0, int64_t R, int64_t K) {
+  const int t = threadIdx.x;
+  if (contiguous_r) {
+    const int rr = t & 127;
+    const int kb = t >> 7;  // 0..1
+    const int64_t gr = r0 + rr;
+#pragma unroll
+    for (int p = 0; p < DK / 2; ++p) {
+      const int kk = kb + 2 * p;
+      const int64_t gk = k0 + kk;
+      S[kk][rr] = (gr < R && gk < K) ? X[gr + gk * ld] : 0.0;
+    }
+  } else {
+    const int kk = t & 15;
+    const int rb = t >> 4;  // 0..15
+    const int64_t gk = k0 + kk;
+#pragma unroll
+    for (int p = 0; p < MT / 16; ++p) {
+      const int rr = rb + 16 * p;
+      const int64_t gr = r0 + rr;
+      S[kk][rr] = (gr < R && gk < K) ? X[gk + gr * ld] : 0.0;
+    }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void GemmMfmaF64Kernel(
+    int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha,
+    const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+    double beta, double* C, int64_t ldc, int lower_only, int64_t sA, int64_t sB, int64_t sC,
+    int64_t n1, int64_t sA2, int64_t sB2) {
+  {
+    const int64_t z = blockIdx.z, z1 = z % n1, z2 = z / n1;
+    A += z1 * sA + z2 * sA2;
+    B += z1 * sB + z2 * sB2;
+    C += z * sC;
+  }
+  __shared__ double As[DK][DLD];
+  __shared__ double Bs[DK][DLD];
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * MT;
+  const int64_t j0 = static_cast<int64_t>(blockIdx.y) * MT;
+  if (lower_only && i0 + MT <= j0) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wi = wave & 1, wj = wave >> 1;  // wavefront's 64 x 64 quadrant
+  const int l15 = lane & 15, lk = lane >> 4;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0;
+
+  for (int64_t k0 = 0; k0 < K; k0 += DK) {
+    StageTileF64(As, A, lda, transA == 0, i0, k0, M, K);
+    StageTileF64(Bs, B, ldb, transB != 0, j0, k0, N, K);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < DK; kk += 4) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = As[kk + lk][wi * 64 + a * 16 + l15];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = Bs[kk + lk][wj * 64 + b * 16 + l15];
+      // D'[j][i] += Bop[k][j] * Aop[i][k]: MFMA "A" operand = B values, "B" operand = A values
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[b], av[a], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // acc[a][b][reg]: i_local = l15 (the MFMA's column), j_local = lk + 4 * reg (its row)
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int64_t i = i0 + wi * 64 + a * 16 + l15;
+    if (i >= M) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + wj * 64 + b * 16 + lk + 4 * r;
+        if (j >= N) continue;
+        double* c = C + i + j * ldc;
+        const double v = alpha * acc[a][b][r];
+        *c = (beta == 0.0) ? v : v + beta * (*c);
+      }
+    }
+  }
+}
+
+int GemmMode() {  // 0 auto, 1 generic, 2 mfma, 3 mfma without the pipelined kernel
+  // (read on every call: eps_set_option("gemm", ...) switches it between products in the tests)
+  const char* e = std::getenv("EPSILON_HIP_GEMM");
+  int mode = 0;
+  if (e && std::strcmp(e, "generic") == 0) mode = 1;
+  if (e && std::strcmp(e, "mfma") == 0) mode = 2;
+  if (e && std::strcmp(e, "mfma_simple") == 0) mode = 3;
   return mode;
 }
 
@@ -551,6 +658,18 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
     hipLaunchKernelGGL(GemmMfmaF32Kernel, grid, dim3(kBlock), 0, s, transA ? 1 : 0,
                        transB ? 1 : 0, M, N, K, static_cast<float>(alpha), A.as<float>(), lda,
                        B.as<float>(), ldb, static_cast<float>(beta), C.as<float>(), ldc,
+                       lower_only ? 1 : 0, sA, sB, sC, n1, sA2, sB2);
+    return;
+  }
+  // fp64: MI355X's f64 matrix peak equals its f64 vector peak (78.6 TFLOP/s), and this plain
+  // (unpipelined) MFMA kernel measured 19.4 TFLOP/s on 4096^3 against 28.9 for the VALU tile
+  // kernel below - so the VALU kernel stays the default and the MFMA one is opt-in
+  // (EPSILON_HIP_GEMM=mfma; kept under test for the day it is pipelined like the f32 one).
+  if (A.dt == F64 && mode >= 2) {
+    dim3 grid(static_cast<unsigned>((M + MT - 1) / MT), static_cast<unsigned>((N + MT - 1) / MT),
+              static_cast<unsigned>(batch));
+    hipLaunchKernelGGL(GemmMfmaF64Kernel, grid, dim3(kBlock), 0, s, transA ? 1 : 0, transB ? 1 : 0, M, N,
+                       K, alpha, A.as<double>(), lda, B.as<double>(), ldb, beta, C.as<double>(), ldc,
                        lower_only ? 1 : 0, sA, sB, sC, n1, sA2, sB2);
     return;
   }

@@ -228,6 +228,30 @@ def test_gemm_mfma_vs_oracle(solve_mod):
     np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-4, atol=1e-3)
 
 
+def test_gemm_f64_mfma_vs_numpy(solve_mod):
+    """Dense*Dense in fp64 on v_mfma_f64_16x16x4_f64 (opt-in kernel; its accumulator map is NOT the
+    f32 one): all four transpose combinations, ragged edges, asymmetric operands, SYRK."""
+    solve_mod.set_option("dtype", "f64")
+    solve_mod.set_option("gemm", "mfma")
+    try:
+        rng = np.random.RandomState(12)
+        for (m, k, n) in [(300, 500, 260), (128, 64, 128), (129, 33, 65), (64, 16, 64), (257, 19, 130)]:
+            for ta in (False, True):
+                for tb in (False, True):
+                    A = rng.randn(*((k, m) if ta else (m, k))) + np.arange(m)[None if ta else slice(None), None if not ta else slice(None)] * 0.01
+                    B = rng.randn(*((n, k) if tb else (k, n)))
+                    _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, tb)
+                    ref = (A.T if ta else A).dot(B.T if tb else B)
+                    np.testing.assert_allclose(C, ref, rtol=1e-12, atol=1e-11)
+        A = rng.randn(200, 700)
+        Am = ir.dense_matrix(A)
+        _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
+        np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-12, atol=1e-11)
+    finally:
+        solve_mod.set_option("gemm", "auto")
+        solve_mod.set_option("dtype", "f32")
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_gemm_long_contraction_split_k(solve_mod, dt):
     """A long contraction into a small result (the X^T R of the multiclass hinge) is split over K
