@@ -194,6 +194,27 @@ def cpu_baseline(At, b, lam, iters_to_eps=None, budget_s=10.0):
             o["time_to_eps_note"] = "Init estimate + %d sweeps (the GPU run's count to OPTIMAL) at the measured CPU rate" % iters_to_eps
         out.append(o)
     c_oracle.set_threads(1)
+    # cross-check of the port's mat-vecs against the BLAS in the reference's own tree (vendored
+    # Eigen, built into oracle/_ref by oracle/Makefile where the reference exists): one A x and one
+    # A^T w through its dgemv_, single thread
+    try:
+        from oracle import ref_lib
+        if ref_lib.available():
+            xx, ww = rng.randn(n), rng.randn(m)
+            ref_lib.dgemv(A[:, :8], xx[:8])  # load the library
+            t0 = time.time()
+            ref_lib.dgemv(A, xx)
+            t_n = time.time() - t0
+            t0 = time.time()
+            ref_lib.dgemv(A, ww, trans=True)
+            t_t = time.time() - t0
+            out[0]["reference_tree_blas"] = {
+                "library": "oracle/_ref/libref.so (third_party/eigen/blas of the reference, g++ -O3 -DNDEBUG)",
+                "dgemv_N_ms": 1e3 * t_n, "dgemv_T_ms": 1e3 * t_t,
+                "note": "the port's sweep is 2 such mat-vecs + the m x m apply: %.0f ms with this BLAS' mat-vecs "
+                        "against %.0f ms measured for the port's whole sweep" % (1e3 * (t_n + t_t), out[0]["ms_per_step"])}
+    except Exception as e:  # the cross-check is optional
+        out[0]["reference_tree_blas"] = {"error": str(e)}
     return out[0], out[-1]
 
 
@@ -341,9 +362,12 @@ def main():
             flops = float(m) * (m + 1) * At.shape[0]  # lower triangle incl. diagonal, 2 flops / MAC
             out["init_breakdown"] = {
                 "gram_syrk_ms": gram_ms,
-                "gram": {"bound": "mfma", "kernel": "GemmMfmaF32PipeKernel<true,true> (SYRK A A^T, lower tiles)",
-                         "achieved": flops / (gram_ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": flops / (gram_ms * 1e-3) / 1e12 / 157.3,
+                "gram": {"bound": "mfma" if args.dtype == "f32" else "valu",
+                         "kernel": ("GemmMfmaF32PipeKernel<true,true> (SYRK A A^T, lower tiles)" if args.dtype == "f32"
+                                    else "GemmGenericKernel<double> (SYRK A A^T, lower tiles; fp64 VALU)"),
+                         "achieved": flops / (gram_ms * 1e-3) / 1e12,
+                         "peak": 157.3 if args.dtype == "f32" else 78.6, "unit": "TFLOP/s",
+                         "frac": flops / (gram_ms * 1e-3) / 1e12 / (157.3 if args.dtype == "f32" else 78.6),
                          "gemm_equivalent_TFLOPs": 2.0 * m * m * At.shape[0] / (gram_ms * 1e-3) / 1e12},
                 "explicit_inverse_ms": (init_prof.get("spd_inverse:%d" % m, (0, 0.0))[1]),
             }

@@ -306,12 +306,21 @@ template <bool CA, bool CB>
 __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
     int64_t M, int64_t N, int64_t K, float alpha, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float beta, float* C, int64_t ldc,
-    int lower_only, int64_t sA, int64_t sB, int64_t sC, int64_t n1, int64_t sA2, int64_t sB2) {
+    int lower_only, int64_t sA, int64_t sB, int64_t sC, int64_t n1, int64_t sA2, int64_t sB2,
+    int64_t lin0, int64_t kchunk, float* __restrict__ P) {
   {
     const int64_t z = blockIdx.z, z1 = z % n1, z2 = z / n1;
     A += z1 * sA + z2 * sA2;
     B += z1 * sB + z2 * sB2;
     C += z * sC;
+  }
+  // split-K form of the compact triangle (the tail tiles of a SYRK, see GemmBatched): blockIdx.y
+  // selects a chunk of K, the raw partial tile goes to P instead of C
+  if (kchunk > 0) {
+    const int64_t k_begin = static_cast<int64_t>(blockIdx.y) * kchunk;
+    A += CA ? k_begin * lda : k_begin;
+    B += CB ? k_begin * ldb : k_begin;
+    K = K - k_begin < kchunk ? K - k_begin : kchunk;
   }
   constexpr int LDA = StageCfg<CA>::LD, LDB = StageCfg<CB>::LD;
   // two LDS stages: slab k+1 is written while slab k is still being read, one barrier per slab
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
   if (lower_only == 2) {
     // compact 1-D grid over the tiles on and below the diagonal (no empty workgroups, and the
     // round-robin of workgroups over the 8 XCDs splits the real tiles evenly)
-    const int64_t lin = blockIdx.x;
+    const int64_t lin = lin0 + blockIdx.x;
     int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= lin) ++I;
     while (I * (I + 1) / 2 > lin) --I;
@@ -435,11 +444,38 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
       for (int r = 0; r < 16; ++r) {
         const int64_t j = lj0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (j < j0 || j >= N) continue;
+        if (P != nullptr) {
+          P[(static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (MT * MT) + (i - i0) +
+            (j - j0) * MT] = acc[a][b][r];
+          continue;
+        }
         float* c = C + i + j * ldc;
         const float v = alpha * acc[a][b][r];
         *c = (beta == 0.0f) ? v : v + beta * (*c);
       }
     }
+  }
+}
+
+// C tile = alpha * (sum of the S partial tiles, in order) + beta * C for the tail tiles of the
+// compact triangle (lin0 + blockIdx.x).
+__global__ __launch_bounds__(kBlock) void SyrkTailFixupKernel(int64_t M, int64_t lin0, int S,
+                                                              const float* __restrict__ P, float alpha,
+                                                              float beta, float* C, int64_t ldc) {
+  const int64_t lin = lin0 + blockIdx.x;
+  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+  while (I * (I + 1) / 2 > lin) --I;
+  const int64_t i0 = I * MT, j0 = (lin - I * (I + 1) / 2) * MT;
+  const float* p0 = P + static_cast<int64_t>(blockIdx.x) * S * (MT * MT);
+  for (int e = threadIdx.x; e < MT * MT; e += kBlock) {
+    const int64_t i = i0 + (e & (MT - 1)), j = j0 + (e >> 7);
+    if (i >= M || j >= M) continue;
+    float sum = p0[e];
+    for (int c = 1; c < S; ++c) sum += p0[static_cast<int64_t>(c) * (MT * MT) + e];
+    float* dst = C + i + j * ldc;
+    const float v = alpha * sum;
+    *dst = (beta == 0.0f) ? v : v + beta * (*dst);
   }
 }
 
@@ -640,18 +676,57 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
       const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
       int lo = lower_only ? 1 : 0;
       static const bool compact = std::getenv("EPSILON_HIP_SYRK_2D") == nullptr;
+      int64_t lin0 = 0, kchunk = 0, tail = 0;
+      int S = 1;
+      float* P = nullptr;
+      std::shared_ptr<Buffer> pbuf;
       if (lower_only && batch == 1 && compact) {
         const int64_t T = (M + MT - 1) / MT;
-        grid = dim3(static_cast<unsigned>(T * (T + 1) / 2), 1, 1);
+        const int64_t total = T * (T + 1) / 2;
+        grid = dim3(static_cast<unsigned>(total), 1, 1);
         lo = 2;
+        // A long contraction (the Gram product: 3160 tiles of ~6 ms each at config 2) runs in
+        // rounds of 512 resident workgroups and ends in a ragged one - 88 tiles on a chip that
+        // holds 512, a seventh round as long as the six full ones.  The tail tiles are split over
+        // K instead (S chunks each, S * tail <= 512: one short round), their partial tiles summed
+        // in a fixed order by a fix-up launch.
+        static const bool split_tail = [] {
+          const char* e = std::getenv("EPSILON_HIP_SYRK_TAIL");
+          return !(e && e[0] == '0');
+        }();
+        const int64_t slots = 512;
+        tail = total % slots;
+        if (split_tail && K >= 8192 && total > slots && tail > 0 && tail <= slots / 2) {
+          S = static_cast<int>(std::min<int64_t>(8, slots / tail));
+          kchunk = ((K + S - 1) / S + MK - 1) / MK * MK;
+          S = static_cast<int>((K + kchunk - 1) / kchunk);
+          pbuf = Runtime::Get().Alloc(static_cast<size_t>(tail) * S * MT * MT * sizeof(float));
+          P = static_cast<float*>(pbuf->p);
+          grid = dim3(static_cast<unsigned>(total - tail), 1, 1);
+        } else {
+          tail = 0;
+        }
       }
-#define EPS_PIPE(CA, CB)                                                                       \
-  hipLaunchKernelGGL((GemmMfmaF32PipeKernel<CA, CB>), grid, dim3(kBlock), 0, s, M, N, K, al,    \
-                     A.as<float>(), lda, B.as<float>(), ldb, be, C.as<float>(), ldc, lo, sA, sB, sC, n1, sA2, sB2)
-      if (!transA && transB) EPS_PIPE(true, true);
-      else if (!transA && !transB) EPS_PIPE(true, false);
-      else if (transA && transB) EPS_PIPE(false, true);
-      else EPS_PIPE(false, false);
+#define EPS_PIPE(CA, CB, GRID, LIN0, KCH, PP)                                                     \
+  hipLaunchKernelGGL((GemmMfmaF32PipeKernel<CA, CB>), GRID, dim3(kBlock), 0, s, M, N, K, al,       \
+                     A.as<float>(), lda, B.as<float>(), ldb, be, C.as<float>(), ldc, lo, sA, sB, sC, n1, sA2, sB2, \
+                     static_cast<int64_t>(LIN0), static_cast<int64_t>(KCH), PP)
+#define EPS_PIPE_ALL(GRID, LIN0, KCH, PP)                          \
+  do {                                                             \
+    if (!transA && transB) EPS_PIPE(true, true, GRID, LIN0, KCH, PP);        \
+    else if (!transA && !transB) EPS_PIPE(true, false, GRID, LIN0, KCH, PP); \
+    else if (transA && transB) EPS_PIPE(false, true, GRID, LIN0, KCH, PP);   \
+    else EPS_PIPE(false, false, GRID, LIN0, KCH, PP);                        \
+  } while (0)
+      EPS_PIPE_ALL(grid, lin0, 0, static_cast<float*>(nullptr));
+      if (tail > 0) {
+        const int64_t first = static_cast<int64_t>(grid.x);
+        dim3 tgrid(static_cast<unsigned>(tail), static_cast<unsigned>(S), 1);
+        EPS_PIPE_ALL(tgrid, first, kchunk, P);
+        hipLaunchKernelGGL(SyrkTailFixupKernel, dim3(static_cast<unsigned>(tail)), dim3(kBlock), 0, s, M,
+                           first, S, P, al, be, C.as<float>(), ldc);
+      }
+#undef EPS_PIPE_ALL
 #undef EPS_PIPE
       return;
     }

@@ -226,6 +226,14 @@ def test_gemm_mfma_vs_oracle(solve_mod):
     Am = ir.dense_matrix(A)
     _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
     np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-4, atol=1e-3)
+    # ... with a long contraction and more lower-triangle tiles than the chip holds at once
+    # (33 * 34 / 2 = 561 = 512 + 49): the 49 tail tiles are split over K and fixed up
+    A = (rng.randn(4160, 8200) / 64).astype(np.float32).astype(np.float64)
+    Am = ir.dense_matrix(A)
+    _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
+    ref = A.dot(A.T)
+    np.testing.assert_allclose(C, ref, rtol=1e-4, atol=1e-4)
+    assert np.array_equal(C, C.T)
 
 
 def test_gemm_f64_mfma_vs_numpy(solve_mod):
