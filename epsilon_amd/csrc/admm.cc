@@ -313,7 +313,7 @@ class ProxADMMSolver final : public Solver {
     ResetGraph();
     const char* env = std::getenv("EPSILON_HIP_FUSED");
     if (env && env[0] == '0') return;
-    if (data_->dtype() != F32 || N_ != 2 || problem_.constraint.size() != 1) return;
+    if (N_ != 2 || problem_.constraint.size() != 1) return;
     if (!b_.data().empty()) return;
     // consensus form: the threshold step averages over the ranks, which the fused pass does not
     if (ShardSpec::Get().active() && ShardSpec::Get().consensus_terms()) return;
@@ -335,7 +335,7 @@ class ProxADMMSolver final : public Solver {
     if (A0.impl().n() != f.n || A1.impl().n() != f.n) return;
     if (!k::LassoFusedSupported(f.m, f.n, L.data(), L.rows())) return;
     if (f.ls.rhs_arg.n != 0 && f.ls.rhs_arg.n != f.m) return;
-    const DType dt = F32;
+    const DType dt = data_->dtype();
     // the six state vectors are slices of ONE buffer, so that a residual check can snapshot the
     // iterates with a single copy (pipelined checks, Solver::Run)
     const int64_t npad = (f.n + 63) / 64 * 64;
@@ -355,7 +355,7 @@ class ProxADMMSolver final : public Solver {
     f.u = state(u_, ck);
     f.y1prev = state(BlockVector(), ck);
     f.p = DVec::Zeros(f.m, dt);
-    f.grid = k::LassoFusedGrid(f.m, f.n);
+    f.grid = k::LassoFusedGrid(f.m, f.n, dt);
     f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
     {
       Comm* comm = Runtime::Get().comm();
@@ -364,7 +364,7 @@ class ProxADMMSolver final : public Solver {
       const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
       // one-shot peer-write exchange inside the sweep's own kernels (kernels_peer.hip) when the
       // ranks share a window and the m-float message fits its slots; RCCL collectives otherwise
-      f.use_peer = sharded && px != nullptr && f.m <= px->slot() && f.ls.Dinv_arg != nullptr &&
+      f.use_peer = dt == F32 && sharded && px != nullptr && f.m <= px->slot() && f.ls.Dinv_arg != nullptr &&
                    !f.ls.Dinv_arg->trans() && f.ls.Dinv_arg->rows() == f.m;
       const int G = f.use_peer ? px->view().G : (comm ? comm->size() : 1);
       f.slab = ((f.m + G - 1) / G + 3) / 4 * 4;
@@ -451,7 +451,7 @@ class ProxADMMSolver final : public Solver {
         DVec slab = D.data().Slice(lo * f.m, cnt * f.m);
         k::Gemv(true, f.m, cnt, D.scale(), slab, f.m, f.p, 0.0, mine.Slice(0, cnt));
       }
-      comm->AllGather(mine.data(), f.wpad.data(), static_cast<size_t>(per), F32);
+      comm->AllGather(mine.data(), f.wpad.data(), static_cast<size_t>(per), f.wpad.dt);
       (void)G;
     } else {
       ApplyInverseFixed();

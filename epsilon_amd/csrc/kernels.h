@@ -62,7 +62,7 @@ struct LassoFusedArgs {
   unsigned* epoch = nullptr;        // optional device counter, incremented once per launch
 };
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda);
-int LassoFusedGrid(int64_t m, int64_t n);
+int LassoFusedGrid(int64_t m, int64_t n, DType dt = F32);
 void LassoFusedPass(const LassoFusedArgs& args);
 // out6 = {||y0||^2, ||y1||^2, ||y0 + y1||^2, ||y1 - y1prev||^2, ||u||^2, peer_err ? 1 : 0} (device
 // doubles), one launch; `work`: 64 * 5 + 1 doubles, zero-initialised once (the last double is a

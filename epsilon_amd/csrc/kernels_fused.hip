@@ -57,6 +57,134 @@ struct FusedScalars {
   float lam, alpha, beta, M;
 };
 
+// ---- the same pass in either precision (the f64 form serves the fp64 mode: the reference's own
+// arithmetic type, linear/linear_map.h:35) ---------------------------------------------------------
+template <class T> struct FusedScalarsT {
+  T kappa, Bs, Cs, a1, lam, alpha, beta, M;
+};
+
+template <class T> __device__ inline T WaveSumT(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <class T> __device__ inline T ScaledZoneOneT(T xi, T lam, T alpha, T beta, T M) {
+  // reference prox/scaled_zone.cc:90-101 with C = 0
+  if (fabs(xi) <= M) return xi;
+  if (xi > M + lam * alpha) return xi - lam * alpha;
+  if (xi < -M - lam * beta) return xi + lam * beta;
+  if (xi > T(0)) return M;
+  return -M;
+}
+
+// One column's elementwise chain (see ChainOne below for the line-by-line correspondence).
+template <class T>
+__device__ inline T ChainOneT(T d, const FusedScalarsT<T>& c, T u, T y0p, T y1p, T* x0o, T* x1o,
+                              T* y0o, T* y1o, T* uo) {
+  const T v0 = ((u - y0p) - y1p) + y0p;
+  const T x0 = c.kappa * d + v0;
+  const T y0 = x0;
+  const T u1 = v0 - y0;
+  const T u2 = u1 + y1p;
+  const T vin = c.Bs * u2;
+  const T xz = ScaledZoneOneT<T>(vin, c.lam, c.alpha, c.beta, c.M);
+  const T x1 = c.Cs * xz;
+  const T y1 = c.a1 * x1;
+  const T u3 = u2 - y1;
+  *x0o = x0;
+  *x1o = x1;
+  *y0o = y0;
+  *y1o = y1;
+  *uo = u3;
+  return ((u3 - y0) - y1) + y0;
+}
+
+// f64 pass: 16-byte loads hold two rows, so 512 threads x 10 chunks own up to 10240 rows.
+template <int NR, int BS>
+__global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernelF64(
+    int64_t m, int64_t n, const double* __restrict__ A, int64_t lda, const double* __restrict__ w,
+    FusedScalarsT<double> c, double* u, double* x0, double* x1, double* y0, double* y1,
+    double* y1prev, double* __restrict__ tpart) {
+  __shared__ double red[2][BS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double2 wv[NR], tp[NR];
+  int64_t row[NR];
+#pragma unroll
+  for (int q = 0; q < NR; ++q) {
+    row[q] = (static_cast<int64_t>(q) * BS + tid) * 2;
+    wv[q] = row[q] < m ? *reinterpret_cast<const double2*>(w + row[q]) : make_double2(0, 0);
+    tp[q] = make_double2(0, 0);
+  }
+  const int64_t npairs = (n + 1) / 2;
+  auto column = [&](int64_t step) -> int64_t {
+    const int64_t jp = blockIdx.x + (step >> 1) * gridDim.x;
+    const int64_t j = 2 * jp + (step & 1);
+    return (jp < npairs && j < n) ? j : -1;
+  };
+  auto load = [&](double2 (&a)[NR], int64_t j) {
+    const double* cp = A + j * lda;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      if (row[q] < m) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(cp + row[q]));
+        a[q] = make_double2(v.x, v.y);
+      } else {
+        a[q] = make_double2(0, 0);
+      }
+    }
+  };
+  double2 cur[NR], nxt[NR];
+  int64_t step = 0;
+  int64_t j = column(0);
+  if (j >= 0) load(cur, j);
+  int par = 0;
+  while (j >= 0) {
+    int64_t jn = column(step + 1);
+    if (jn < 0 && ((step + 1) & 1)) jn = column(step + 2);
+    const int64_t step_n = (jn >= 0 && column(step + 1) < 0) ? step + 2 : step + 1;
+    if (jn >= 0) load(nxt, jn);
+    const double uj = u[j], y0j = y0[j], y1j = y1[j];
+    double d = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      d += cur[q].x * wv[q].x;
+      d += cur[q].y * wv[q].y;
+    }
+    d = WaveSumT<double>(d);
+    if (lane == 0) red[par][wave] = d;
+    __syncthreads();
+    d = red[par][0];
+#pragma unroll
+    for (int w2 = 1; w2 < BS / 64; ++w2) d += red[par][w2];
+    par ^= 1;
+    double nx0, nx1, ny0, ny1, nu;
+    const double v0n = ChainOneT<double>(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
+    if (tid == 0) {
+      y1prev[j] = y1j;
+      x0[j] = nx0;
+      x1[j] = nx1;
+      y0[j] = ny0;
+      y1[j] = ny1;
+      u[j] = nu;
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      tp[q].x += cur[q].x * v0n;
+      tp[q].y += cur[q].y * v0n;
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) cur[q] = nxt[q];
+    j = jn;
+    step = step_n;
+  }
+  double* out = tpart + static_cast<int64_t>(blockIdx.x) * m;
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    if (row[q] < m) *reinterpret_cast<double2*>(out + row[q]) = tp[q];
+}
+
 // One column's elementwise chain.  Returns v0' (input of the next sweep's forward pass).
 __device__ inline float ChainOne(float d, const FusedScalars& c, float u, float y0p, float y1p,
                                  float* x0o, float* x1o, float* y0o, float* y1o, float* uo) {
@@ -324,9 +452,10 @@ __device__ inline double WaveSumD(double v) {
   return v;
 }
 
+template <class T>
 __global__ __launch_bounds__(kBlock) void LassoFusedNormsKernel(
-    int64_t n, const float* __restrict__ u, const float* __restrict__ y0, const float* __restrict__ y1,
-    const float* __restrict__ y1prev, double* partial, unsigned* ticket, double* out,
+    int64_t n, const T* __restrict__ u, const T* __restrict__ y0, const T* __restrict__ y1,
+    const T* __restrict__ y1prev, double* partial, unsigned* ticket, double* out,
     const unsigned* peer_err) {
   __shared__ double red[kBlock / 64][5];
   __shared__ bool last;
@@ -383,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void LassoFusedNormsKernel(
 void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& y1prev, double* out6,
                      const DVec& work, const unsigned* peer_err) {
   const int64_t n = u.n;
-  EPS_CHECK(u.dt == F32 && y0.n == n && y1.n == n && y1prev.n == n);
+  EPS_CHECK(y0.n == n && y1.n == n && y1prev.n == n && y0.dt == u.dt && y1.dt == u.dt && y1prev.dt == u.dt);
   EPS_CHECK(work.dt == F64 && work.n >= kNormBlocks * 5 + 1);
   int64_t grid = (n + 4 * kBlock - 1) / (4 * kBlock);
   if (grid > kNormBlocks) grid = kNormBlocks;
@@ -391,15 +520,21 @@ void LassoFusedNorms(const DVec& u, const DVec& y0, const DVec& y1, const DVec& 
   double* partial = work.as<double>();
   unsigned* ticket = reinterpret_cast<unsigned*>(partial + kNormBlocks * 5);  // zero between launches
   ProfScope prof("lasso_fused_norms", n);
-  hipLaunchKernelGGL(LassoFusedNormsKernel, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
-                     Runtime::Get().stream(), n, u.as<float>(), y0.as<float>(), y1.as<float>(),
-                     y1prev.as<float>(), partial, ticket, out6, peer_err);
+  if (u.dt == F32)
+    hipLaunchKernelGGL(LassoFusedNormsKernel<float>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                       Runtime::Get().stream(), n, u.as<float>(), y0.as<float>(), y1.as<float>(),
+                       y1prev.as<float>(), partial, ticket, out6, peer_err);
+  else
+    hipLaunchKernelGGL(LassoFusedNormsKernel<double>, dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0,
+                       Runtime::Get().stream(), n, u.as<double>(), y0.as<double>(), y1.as<double>(),
+                       y1prev.as<double>(), partial, ticket, out6, peer_err);
   EPS_HIP(hipGetLastError());
 }
 
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda) {
-  return A.dt == F32 && m >= 4 && m % 4 == 0 && lda % 4 == 0 && m <= 20 * 1024 && n >= 1 &&
-         (reinterpret_cast<uintptr_t>(A.data()) % 16 == 0);
+  if (n < 1 || reinterpret_cast<uintptr_t>(A.data()) % 16 != 0) return false;
+  if (A.dt == F32) return m >= 4 && m % 4 == 0 && lda % 4 == 0 && m <= 20 * 1024;
+  return m >= 2 && m % 2 == 0 && lda % 2 == 0 && m <= 10 * 1024;  // f64: two rows per 16-byte load
 }
 
 // Threads per workgroup of the pass: 512 when the rows do not fit 256 threads (m > 10240).
@@ -408,19 +543,22 @@ bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda) {
 // on 5e4 columns - one column in flight per CU instead of two), two per CU are equal; the halved
 // number of partial vectors does not pay either, the reduce-exchange kernel behind the pass is
 // latency-bound (11.5 us at 242 partials, 12.5 at 448).
-int LassoFusedBlock(int64_t m, int64_t n) {
+int LassoFusedBlock(int64_t m, int64_t n, DType dt) {
   (void)n;
+  if (dt == F64) return m > 5 * 1024 ? 512 : 256;
   if (m > 10 * 1024) return 512;
   static const char* env = std::getenv("EPSILON_HIP_FUSED_BLOCK");
   if (env && std::atoi(env) == 512 && m >= 2048) return 512;
   return 256;
 }
 
-int LassoFusedGrid(int64_t m, int64_t n) {
+int LassoFusedGrid(int64_t m, int64_t n, DType dt) {
   int64_t npairs = (n + 1) / 2;
   // two 256-thread workgroups per CU; the 512-thread form with up to 5 row chunks per thread
-  // (m <= 10240) also fits twice, above that once
-  int64_t g = (LassoFusedBlock(m, n) == 512 && m > 10 * 1024) ? 256 : 512;
+  // (m <= 10240 in f32) also fits twice, above that once
+  const int64_t rows_per_chunk = dt == F32 ? 4 : 2;
+  const bool one_per_cu = LassoFusedBlock(m, n, dt) == 512 && m > 512 * 5 * rows_per_chunk;
+  int64_t g = one_per_cu ? 256 : 512;
   static const char* env = std::getenv("EPSILON_HIP_FUSED_GRID");  // tuning knob
   if (env && std::atoi(env) > 0) g = std::atoi(env);
   if (g > npairs) g = npairs;
@@ -433,14 +571,46 @@ int LassoFusedGrid(int64_t m, int64_t n) {
   return static_cast<int>(g < 1 ? 1 : g);
 }
 
+namespace {
+void LassoFusedPassF64(const LassoFusedArgs& a, int grid, int block) {
+  FusedScalarsT<double> c{a.kappa, a.Bs, a.Cs, a.a1, a.lam, a.sz_alpha, a.sz_beta, a.sz_M};
+  EPS_CHECK_MSG(a.epoch == nullptr, "the peer exchange is f32 only");
+  ProfScope prof("lasso_fused", a.m, a.n);
+  const int64_t need = (a.m + 2 * block - 1) / (2 * block);  // double2 row chunks per thread
+  hipStream_t s = Runtime::Get().stream();
+#define EPS_FUSED_CASE64(NRV, BSV)                                                                     \
+  hipLaunchKernelGGL((LassoFusedStreamKernelF64<NRV, BSV>), dim3(grid), dim3(BSV), 0, s, a.m, a.n,      \
+                     a.A.as<double>(), a.lda, a.w.as<double>(), c, a.u.as<double>(), a.x0.as<double>(), \
+                     a.x1.as<double>(), a.y0.as<double>(), a.y1.as<double>(), a.y1prev.as<double>(),    \
+                     a.tpart.as<double>())
+  if (block == 256) {
+    if (need <= 1) EPS_FUSED_CASE64(1, 256);
+    else if (need <= 2) EPS_FUSED_CASE64(2, 256);
+    else if (need <= 4) EPS_FUSED_CASE64(4, 256);
+    else if (need <= 8) EPS_FUSED_CASE64(8, 256);
+    else EPS_FUSED_CASE64(10, 256);
+  } else {
+    if (need <= 8) EPS_FUSED_CASE64(8, 512);
+    else EPS_FUSED_CASE64(10, 512);
+  }
+#undef EPS_FUSED_CASE64
+  EPS_HIP(hipGetLastError());
+}
+}  // namespace
+
 void LassoFusedPass(const LassoFusedArgs& a) {
   EPS_CHECK(LassoFusedSupported(a.m, a.n, a.A, a.lda));
-  EPS_CHECK(a.w.n == a.m && a.w.dt == F32);
+  const DType dt = a.A.dt;
+  EPS_CHECK(a.w.n == a.m && a.w.dt == dt);
   for (const DVec* v : {&a.u, &a.x0, &a.x1, &a.y0, &a.y1, &a.y1prev})
-    EPS_CHECK(v->n == a.n && v->dt == F32);
-  const int grid = LassoFusedGrid(a.m, a.n);
-  const int block = LassoFusedBlock(a.m, a.n);
-  EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == F32);
+    EPS_CHECK(v->n == a.n && v->dt == dt);
+  const int grid = LassoFusedGrid(a.m, a.n, dt);
+  const int block = LassoFusedBlock(a.m, a.n, dt);
+  EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == dt);
+  if (dt == F64) {
+    LassoFusedPassF64(a, grid, block);
+    return;
+  }
   EPS_CHECK(reinterpret_cast<uintptr_t>(a.w.data()) % 16 == 0 &&
             reinterpret_cast<uintptr_t>(a.tpart.data()) % 16 == 0);
   FusedScalars c;

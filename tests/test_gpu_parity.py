@@ -685,6 +685,40 @@ def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
         np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-3, atol=1e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (2, 7), (1030, 2049), (5200, 5301)])
+def test_fused_sweep_fp64(solve_mod, shape):
+    """The fused pass in fp64 (the reference's arithmetic type; two rows per 16-byte load, 512-thread
+    workgroups above 5120 rows): same stopping sweep and residuals as the oracle, iterates to fp64
+    rounding of both the unfused operator path and the oracle."""
+    m, n = shape
+    prob, info = problems.lasso(m, n, seed=6)
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    sb = wire.SolverParams(max_iterations=200).SerializeToString()
+    solve_mod.set_option("dtype", "f64")
+    try:
+        solve_mod.set_option("fused", "1")
+        solve_mod.profile_reset()
+        solve_mod.profile_enable(True)
+        st_f, x_f = solve_mod.solve(pb, [], sb, data)
+        tags = solve_mod.profile_dump()
+        solve_mod.profile_enable(False)
+        solve_mod.set_option("fused", "0")
+        st_g, x_g = solve_mod.solve(pb, [], sb, data)
+    finally:
+        solve_mod.set_option("fused", "1")
+        solve_mod.set_option("dtype", "f32")
+    assert any(t.startswith("lasso_fused:%dx%d" % (m, n)) for t in tags), sorted(tags)
+    st_o, x_o = orc.solve(pb, [], sb, data)
+    sf, sg, so = (wire.SolverStatus.FromString(s) for s in (st_f, st_g, st_o))
+    assert sf.state == sg.state == so.state == wire.SolverStatus.OPTIMAL
+    assert sf.num_iterations == sg.num_iterations == so.num_iterations
+    for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
+        np.testing.assert_allclose(getattr(sf.residuals, f), getattr(so.residuals, f), rtol=1e-8, atol=1e-11)
+    for k in x_o:
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_g[k]), rtol=1e-9, atol=1e-11, err_msg=k)
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-8, atol=1e-10, err_msg=k)
+
+
 @pytest.mark.parametrize("apply_mode", ["slab", "replicated"])
 def test_fused_sweep_sharded(solve_mod, tmp_path, apply_mode):
     """Fused pass on column slabs with the all-reduce between the pass and the cached-inverse
