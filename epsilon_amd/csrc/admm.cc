@@ -754,6 +754,7 @@ class ProxADMMTwoBlockSolver final : public Solver {
     zero_f_ = pb::ProxFunction();
     constr_prox_->Init(ProxOperatorArg(zero_f_, data_.get(), H, A));
     GlobalDims(H.A, &m_, &n_);
+    constr_H_ = H;
 
     EPS_CHECK_MSG(problem_.objective.expression_type == pb::Expression::ADD, "objective is not ADD");
     N_ = static_cast<int>(problem_.objective.arg.size());
@@ -786,6 +787,7 @@ class ProxADMMTwoBlockSolver final : public Solver {
     finished_ = false;
     status_ = pb::SolverStatus();
     initialized_ = true;
+    TryEnableFused();
     Runtime::Get().Sync();
     init_seconds_ = Now() - t0;
   }
@@ -793,7 +795,117 @@ class ProxADMMTwoBlockSolver final : public Solver {
   BlockVector GetSolution() override { return x_; }
 
  protected:
+  // ---- fused sweep for "least squares + separable threshold" problems, two-block form -----------
+  // [SUM_SQUARE with a dense argument map, scaled-zone prox], one constraint a0 x0 + a1 x1 = 0
+  // without a constant: the x-updates are the same two operators as in the multi-block driver, the
+  // z-update is the closed-form projection onto the constraint, so one pass over the data matrix
+  // does a whole sweep (kernels_fused.hip, chain 1).  f32, single GPU.
+  void TryEnableFused() {
+    fused_ = false;
+    const char* env = std::getenv("EPSILON_HIP_FUSED");
+    if (env && env[0] == '0') return;
+    if (data_->dtype() != F32 || N_ != 2 || problem_.constraint.size() != 1) return;
+    if (ShardSpec::Get().active()) return;
+    if (!constr_H_.b.data().empty()) return;
+    FusedState f;
+    if (!prox_[0]->DescribeLeastSquares(&f.ls) || !prox_[1]->DescribeScaledZone(&f.sz)) return;
+    if (f.ls.var_key == f.sz.var_key) return;
+    const std::string ck = affine::constraint_key(0);
+    const BlockMatrix& H = constr_H_.A;
+    if (H.data().size() != 2 || !H.has_key(ck, f.ls.var_key) || !H.has_key(ck, f.sz.var_key)) return;
+    const LinearMap& H0 = H(ck, f.ls.var_key);
+    const LinearMap& H1 = H(ck, f.sz.var_key);
+    if (H0.impl().type() != SCALAR_MATRIX || H1.impl().type() != SCALAR_MATRIX) return;
+    f.a0 = GetScalar(H0);
+    f.a1 = GetScalar(H1);
+    if (f.a0 == 0 || f.a1 == 0) return;
+    const DenseMatrixImpl& L = *f.ls.L_arg_var;
+    if (L.trans()) return;
+    f.m = L.rows();
+    f.n = L.cols();
+    if (H0.impl().n() != f.n || H1.impl().n() != f.n) return;
+    if (!k::LassoFusedSupported(f.m, f.n, L.data(), L.rows())) return;
+    if (f.ls.rhs_arg.n != 0 && f.ls.rhs_arg.n != f.m) return;
+    const DenseMatrixImpl& D = *f.ls.Dinv_arg;
+    if (D.trans() || D.rows() != f.m) return;
+    const DType dt = F32;
+    auto state = [&](const BlockVector& src, const std::string& key) {
+      DVec v = DVec::Zeros(f.n, dt);
+      if (src.has_key(key)) k::Copy(v, src(key));
+      return v;
+    };
+    f.x0 = state(x_, f.ls.var_key);
+    f.x1 = state(x_, f.sz.var_key);
+    f.z0 = state(z_, f.ls.var_key);
+    f.z1 = state(z_, f.sz.var_key);
+    f.u0 = state(u_, f.ls.var_key);
+    f.u1 = state(u_, f.sz.var_key);
+    f.z0p = DVec::Zeros(f.n, dt);
+    f.z1p = DVec::Zeros(f.n, dt);
+    f.p = DVec::Zeros(f.m, dt);
+    f.w = DVec::Zeros(f.m, dt);
+    f.grid = k::LassoFusedGrid(f.m, f.n, dt);
+    f.tpart = DVec::Empty(static_cast<int64_t>(f.grid) * f.m, dt);
+    fs_ = f;
+    // the generic containers become views of the fused state
+    auto two = [&](const DVec& a, const DVec& b) {
+      BlockVector v;
+      v.Set(fs_.ls.var_key, a);
+      v.Set(fs_.sz.var_key, b);
+      return v;
+    };
+    x_ = two(fs_.x0, fs_.x1);
+    z_ = two(fs_.z0, fs_.z1);
+    u_ = two(fs_.u0, fs_.u1);
+    z_prev_ = two(fs_.z0p, fs_.z1p);
+    fused_ = true;
+    // p = rhs_arg - L(arg, var) (z0 - u0) of the current state, w = Dinv_arg p
+    DVec v0 = fs_.z0.Clone();
+    k::Axpby(v0, -1.0, fs_.u0, 1.0);
+    L.Apply(-1.0, v0, 0.0, fs_.p);
+    if (fs_.ls.rhs_arg.n != 0) k::Axpby(fs_.p, 1.0, fs_.ls.rhs_arg, 1.0);
+    D.Apply(1.0, fs_.p, 0.0, fs_.w);
+  }
+
+  void FusedSweep() {
+    FusedState& f = fs_;
+    const DenseMatrixImpl& L = *f.ls.L_arg_var;
+    k::LassoFusedArgs a;
+    a.m = f.m;
+    a.n = f.n;
+    a.lda = L.rows();
+    a.A = L.data();
+    a.w = f.w;
+    a.kappa = -L.scale();
+    a.Bs = f.sz.Bs;
+    a.Cs = f.sz.Cs;
+    a.a1 = f.a1;
+    a.a0 = f.a0;
+    a.lam = f.sz.lam;
+    a.sz_alpha = f.sz.alpha;
+    a.sz_beta = f.sz.beta;
+    a.sz_M = f.sz.M;
+    a.chain = 1;
+    a.u = f.u0;
+    a.x0 = f.x0;
+    a.x1 = f.x1;
+    a.y0 = f.z0;
+    a.y1 = f.z1;
+    a.y1prev = f.z0p;
+    a.e0 = f.u1;
+    a.e1 = f.z1p;
+    a.tpart = f.tpart;
+    k::LassoFusedPass(a);
+    k::ReducePartials(f.m, f.grid, f.tpart, -L.scale(), 0.0, f.p,
+                      f.ls.rhs_arg.n != 0 ? &f.ls.rhs_arg : nullptr);
+    f.ls.Dinv_arg->Apply(1.0, f.p, 0.0, f.w);
+  }
+
   void Sweep() override {  // :97-112
+    if (fused_) {
+      FusedSweep();
+      return;
+    }
     z_prev_ = z_;
     BlockVector zu = z_ - u_;
     x_ = BlockVector();
@@ -830,6 +942,17 @@ class ProxADMMTwoBlockSolver final : public Solver {
   std::vector<std::unique_ptr<ProxOperator>> prox_;
   std::vector<std::set<std::string>> arg_shards_;
   std::unique_ptr<ProxOperator> constr_prox_;
+  AffineOperator constr_H_;
+  struct FusedState {
+    LeastSquaresDesc ls;
+    ScaledZoneDesc sz;
+    double a0 = 1, a1 = -1;
+    int64_t m = 0, n = 0;
+    int grid = 0;
+    DVec x0, x1, z0, z1, u0, u1, z0p, z1p, p, w, tpart;
+  };
+  bool fused_ = false;
+  FusedState fs_;
   BlockVector x_, z_, u_, z_prev_;
 };
 

@@ -60,6 +60,12 @@ struct LassoFusedArgs {
   DVec u, x0, x1, y0, y1, y1prev;   // n each, updated in place
   DVec tpart;                       // LassoFusedGrid(m, n) * m: per-workgroup partials of A v0'
   unsigned* epoch = nullptr;        // optional device counter, incremented once per launch
+  // chain = 1: the two-block driver's sweep (prox_admm_two_block.cc:97-112); the arrays then mean
+  // u -> u0, y0 -> z0, y1 -> z1, y1prev -> z0_prev, e0 -> u1, e1 -> z1_prev; a0, a1: the consensus
+  // constraint a0 x0 + a1 x1 = 0 the z-update projects onto.  f32 only.
+  int chain = 0;
+  double a0 = 1;
+  DVec e0, e1;
 };
 bool LassoFusedSupported(int64_t m, int64_t n, const DVec& A, int64_t lda);
 int LassoFusedGrid(int64_t m, int64_t n, DType dt = F32);

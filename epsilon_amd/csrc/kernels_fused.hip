@@ -55,7 +55,16 @@ struct FusedScalars {
   float kappa;  // x0 = v0 + kappa * d
   float Bs, Cs, a1;
   float lam, alpha, beta, M;
+  float a0, inv_aa;  // two-block form: constraint a0 x0 + a1 x1 = 0, 1 / (a0^2 + a1^2)
 };
+
+// One column of the TWO-BLOCK driver's sweep (reference algorithms/prox_admm_two_block.cc:97-112):
+//   zu = z - u ;  x0 = prox_0(zu)_0 = v0 + kappa d ;  x1 = prox_1(zu)_1 (scaled zone) ;
+//   z = projection of x + u onto {a0 z0 + a1 z1 = 0} ;  u += x - z.
+// Returns the next sweep's prox-0 input z0' - u0'.
+__device__ inline float ChainTwoBlock(float d, const FusedScalars& c, float z0p, float z1p, float u0p,
+                                      float u1p, float* x0o, float* x1o, float* z0o, float* z1o,
+                                      float* u0o, float* u1o);
 
 // ---- the same pass in either precision (the f64 form serves the fp64 mode: the reference's own
 // arithmetic type, linear/linear_map.h:35) ---------------------------------------------------------
@@ -208,6 +217,29 @@ __device__ inline float ChainOne(float d, const FusedScalars& c, float u, float 
   return ((u3 - y0) - y1) + y0;
 }
 
+__device__ inline float ChainTwoBlock(float d, const FusedScalars& c, float z0p, float z1p, float u0p,
+                                      float u1p, float* x0o, float* x1o, float* z0o, float* z1o,
+                                      float* u0o, float* u1o) {
+  const float v0 = z0p - u0p;
+  const float v1 = z1p - u1p;
+  const float x0 = c.kappa * d + v0;
+  const float x1 = c.Cs * ScaledZoneOne(c.Bs * v1, c.lam, c.alpha, c.beta, c.M);
+  const float w0 = x0 + u0p;
+  const float w1 = x1 + u1p;
+  const float t = (c.a0 * w0 + c.a1 * w1) * c.inv_aa;
+  const float z0 = w0 - c.a0 * t;
+  const float z1 = w1 - c.a1 * t;
+  const float u0 = u0p + (x0 - z0);
+  const float u1 = u1p + (x1 - z1);
+  *x0o = x0;
+  *x1o = x1;
+  *z0o = z0;
+  *z1o = z1;
+  *u0o = u0;
+  *u1o = u1;
+  return z0 - u0;
+}
+
 template <int NR>
 __global__ __launch_bounds__(kBlock, 2) void LassoFusedKernel(
     int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
@@ -313,11 +345,13 @@ __global__ __launch_bounds__(kBlock, 2) void LassoFusedKernel(
 // at all times.  Same arithmetic per column, bit-identical state.
 // BS threads own the m rows: 256 (two workgroups per CU) up to m = 10240; 512 (one workgroup of 8
 // waves per CU) up to m = 20480 (6.37 TB/s on 2e4 x 5e4).
-template <int NR, int BS>
+// MODE 0: the multi-block driver's chain (ChainOne).  MODE 1: the two-block driver's (ChainTwoBlock);
+// the state arrays then mean u -> u0, y0 -> z0, y1 -> z1, y1prev -> z0_prev, e0 -> u1, e1 -> z1_prev.
+template <int NR, int BS, int MODE>
 __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
     int64_t m, int64_t n, const float* __restrict__ A, int64_t lda, const float* __restrict__ w,
     FusedScalars c, float* u, float* x0, float* x1, float* y0, float* y1, float* y1prev,
-    float* __restrict__ tpart, unsigned* epoch) {
+    float* __restrict__ tpart, unsigned* epoch, float* e0, float* e1) {
   constexpr int kBlock = BS;  // (shadows the file-level constant inside this kernel)
   __shared__ float red[2][kBlock / 64];
   // sweep counter of the peer exchange (kernels_peer.hip): the two exchange kernels that follow
@@ -371,6 +405,8 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
     const int64_t step_n = (jn >= 0 && column(step + 1) < 0) ? step + 2 : step + 1;
     if (jn >= 0) load(nxt, jn);
     const float uj = u[j], y0j = y0[j], y1j = y1[j];
+    float u1j = 0.0f;
+    if (MODE == 1) u1j = e0[j];
     float d = 0.0f;
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
@@ -386,15 +422,31 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
 #pragma unroll
     for (int wv2 = 4; wv2 < kBlock / 64; ++wv2) d += red[par][wv2];
     par ^= 1;
-    float nx0, nx1, ny0, ny1, nu;
-    const float v0n = ChainOne(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
-    if (tid == 0) {
-      y1prev[j] = y1j;
-      x0[j] = nx0;
-      x1[j] = nx1;
-      y0[j] = ny0;
-      y1[j] = ny1;
-      u[j] = nu;
+    float v0n;
+    if (MODE == 0) {
+      float nx0, nx1, ny0, ny1, nu;
+      v0n = ChainOne(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
+      if (tid == 0) {
+        y1prev[j] = y1j;
+        x0[j] = nx0;
+        x1[j] = nx1;
+        y0[j] = ny0;
+        y1[j] = ny1;
+        u[j] = nu;
+      }
+    } else {
+      float nx0, nx1, nz0, nz1, nu0, nu1;
+      v0n = ChainTwoBlock(d, c, y0j, y1j, uj, u1j, &nx0, &nx1, &nz0, &nz1, &nu0, &nu1);
+      if (tid == 0) {
+        y1prev[j] = y0j;  // z_prev
+        e1[j] = y1j;
+        x0[j] = nx0;
+        x1[j] = nx1;
+        y0[j] = nz0;
+        y1[j] = nz1;
+        u[j] = nu0;
+        e0[j] = nu1;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
@@ -417,15 +469,21 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
 template <int NR, int BS>
 void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, const float* w,
                  const FusedScalars& c, float* u, float* x0, float* x1, float* y0, float* y1,
-                 float* y1prev, float* tpart, unsigned* epoch) {
+                 float* y1prev, float* tpart, unsigned* epoch, int chain, float* e0, float* e1) {
+  if (chain == 1) {
+    hipLaunchKernelGGL((LassoFusedStreamKernel<NR, BS, 1>), dim3(grid), dim3(BS), 0,
+                       Runtime::Get().stream(), m, n, A, lda, w, c, u, x0, x1, y0, y1, y1prev, tpart,
+                       epoch, e0, e1);
+    return;
+  }
   // default: the streaming kernel (6.0 vs 5.75 TB/s on the 1e4 x 5e4 matrix); "pair" selects the
   // two-column form (256-thread workgroups only)
   static const char* env = std::getenv("EPSILON_HIP_FUSED_KERNEL");
   const bool stream = !(env && env[0] == 'p') || BS != 256;
   if (stream) {
-    hipLaunchKernelGGL((LassoFusedStreamKernel<NR, BS>), dim3(grid), dim3(BS), 0,
+    hipLaunchKernelGGL((LassoFusedStreamKernel<NR, BS, 0>), dim3(grid), dim3(BS), 0,
                        Runtime::Get().stream(), m, n, A, lda, w, c, u, x0, x1, y0, y1, y1prev,
-                       tpart, epoch);
+                       tpart, epoch, e0, e1);
     return;
   }
   if constexpr (BS == 256)
@@ -608,6 +666,7 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   const int block = LassoFusedBlock(a.m, a.n, dt);
   EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == dt);
   if (dt == F64) {
+    EPS_CHECK_MSG(a.chain == 0, "the two-block chain is f32 only");
     LassoFusedPassF64(a, grid, block);
     return;
   }
@@ -622,12 +681,16 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   c.alpha = static_cast<float>(a.sz_alpha);
   c.beta = static_cast<float>(a.sz_beta);
   c.M = static_cast<float>(a.sz_M);
+  c.a0 = static_cast<float>(a.a0);
+  c.inv_aa = static_cast<float>(1.0 / (a.a0 * a.a0 + a.a1 * a.a1));
+  if (a.chain == 1) EPS_CHECK(a.e0.n == a.n && a.e1.n == a.n && a.e0.dt == F32 && a.e1.dt == F32);
   ProfScope prof("lasso_fused", a.m, a.n);
   const int64_t need = (a.m + 4 * block - 1) / (4 * block);  // float4 row chunks per thread
 #define EPS_FUSED_CASE(NRV, BSV)                                                                      \
   LaunchFused<NRV, BSV>(grid, a.m, a.n, a.A.as<float>(), a.lda, a.w.as<float>(), c, a.u.as<float>(), \
                         a.x0.as<float>(), a.x1.as<float>(), a.y0.as<float>(), a.y1.as<float>(),      \
-                        a.y1prev.as<float>(), a.tpart.as<float>(), a.epoch)
+                        a.y1prev.as<float>(), a.tpart.as<float>(), a.epoch, a.chain,         \
+                        a.chain == 1 ? a.e0.as<float>() : nullptr, a.chain == 1 ? a.e1.as<float>() : nullptr)
   if (block == 256) {
     if (need <= 1) EPS_FUSED_CASE(1, 256);
     else if (need <= 2) EPS_FUSED_CASE(2, 256);

@@ -475,6 +475,28 @@ class SumSquareProx final : public ProxOperator {
   // dense.  Then Solve(b_ + v)[var] = v_c + kappa * A^T (Dinv_arg (rhs_arg + kappa * A v_c)).
   bool DescribeLeastSquares(LeastSquaresDesc* d) const override {
     const std::vector<std::string>& p = chol_.order();
+    if (p.size() == 2 && var_keys_.size() == 1) {
+      // Two-block driver: A = I on the term's own variable, whose id is then both a column and a
+      // row key (prox_admm_two_block.cc:70-75), so the KKT matrix has the two keys [var, arg],
+      // M(var, var) = I, and Solve(b_ + v)[var] = v + kappa A^T (Dinv_arg (rhs_arg + kappa A v)) again.
+      const std::string &vk = p[0], &ak = p[1];
+      if (vk != *var_keys_.begin()) return false;
+      const BlockMatrix& L = chol_.L();
+      const BlockMatrix& Di = chol_.D_inv();
+      if (!L.has_key(ak, vk) || !Di.has_key(vk, vk) || !Di.has_key(ak, ak)) return false;
+      if (Di(vk, vk).impl().type() != SCALAR_MATRIX || GetScalar(Di(vk, vk)) != 1.0) return false;
+      if (L(ak, vk).impl().type() != DENSE_MATRIX || Di(ak, ak).impl().type() != DENSE_MATRIX)
+        return false;
+      for (const auto& kv : b_.data())
+        if (kv.first != ak) return false;
+      d->constraint_key = vk;
+      d->var_key = vk;
+      d->arg_key = ak;
+      d->L_arg_var = std::static_pointer_cast<const DenseMatrixImpl>(L(ak, vk).ptr());
+      d->Dinv_arg = std::static_pointer_cast<const DenseMatrixImpl>(Di(ak, ak).ptr());
+      if (b_.has_key(ak)) d->rhs_arg = b_(ak);
+      return true;
+    }
     if (p.size() != 3 || var_keys_.size() != 1) return false;
     const std::string &ck = p[0], &vk = p[1], &ak = p[2];
     if (vk != *var_keys_.begin()) return false;

@@ -685,6 +685,52 @@ def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
         np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-3, atol=1e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (8, 21), (4100, 4301)])
+@pytest.mark.parametrize("kind", ["lasso", "deadzone"])
+def test_fused_sweep_two_block_driver(solve_mod, shape, kind):
+    """The same one-pass sweep for the TWO_BLOCK driver (prox_admm_two_block.cc:96-133): Jacobi
+    x-updates, closed-form projection onto the consensus constraint, dual ascent - against the
+    unfused operator path and the oracle."""
+    solve_mod.set_option("dtype", "f32")
+    m, n = shape
+    if kind == "lasso":
+        prob, info = problems.lasso(m, n, seed=7)
+    else:
+        A, b = problems.regression_data(m, n, seed=7)
+        lam = 0.3 * np.abs(A.T.dot(b)).max()
+        x = ir.variable(n, 1, problems.LASSO_COPY)
+        y = ir.variable(n, 1, problems.LASSO_VAR)
+        f0 = ir.prox(ProxFunction.SUM_SQUARE, ir.add(ir.linear_map(ir.dense_matrix(A), x),
+                                                     ir.linear_map(ir.scalar(-1, m), ir.constant(b))))
+        f1 = ir.prox(ProxFunction.SUM_DEADZONE, ir.linear_map(ir.scalar(2.0, n), y), alpha=lam,
+                     scaled_zone_params=wire.ProxScaledZoneParams(m=0.05))
+        prob = ir.Problem([f0, f1], [ir.zero(ir.add(ir.linear_map(ir.scalar(2.0, n), x),
+                                                   ir.linear_map(ir.scalar(-2.0, n), y)))])
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    sb = wire.SolverParams(max_iterations=300, solver=1).SerializeToString()
+    try:
+        solve_mod.set_option("fused", "1")
+        solve_mod.profile_reset()
+        solve_mod.profile_enable(True)
+        st_f, x_f = solve_mod.solve(pb, [], sb, data)
+        tags = solve_mod.profile_dump()
+        solve_mod.profile_enable(False)
+        solve_mod.set_option("fused", "0")
+        st_g, x_g = solve_mod.solve(pb, [], sb, data)
+    finally:
+        solve_mod.set_option("fused", "1")
+    assert any(t.startswith("lasso_fused") for t in tags), sorted(tags)
+    st_o, x_o = orc.solve(pb, [], sb, data)
+    sf, sg, so = (wire.SolverStatus.FromString(s) for s in (st_f, st_g, st_o))
+    assert sf.state == sg.state == so.state
+    assert sf.num_iterations == sg.num_iterations == so.num_iterations
+    for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
+        np.testing.assert_allclose(getattr(sf.residuals, f), getattr(so.residuals, f), rtol=3e-3, atol=1e-5)
+    for k in x_o:
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_g[k]), rtol=1e-4, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-3, atol=1e-4, err_msg=k)
+
+
 @pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (2, 7), (1030, 2049), (5200, 5301)])
 def test_fused_sweep_fp64(solve_mod, shape):
     """The fused pass in fp64 (the reference's arithmetic type; two rows per 16-byte load, 512-thread
