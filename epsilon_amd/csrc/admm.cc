@@ -319,6 +319,7 @@ class ProxADMMSolver final : public Solver {
     if (ShardSpec::Get().active() && ShardSpec::Get().consensus_terms()) return;
     FusedState f;
     if (!prox_[0]->DescribeLeastSquares(&f.ls) || !prox_[1]->DescribeScaledZone(&f.sz)) return;
+    if ((f.sz.alpha_vec.n > 0 || f.sz.beta_vec.n > 0) && data_->dtype() != F32) return;
     const std::string ck = affine::constraint_key(0);
     if (f.ls.constraint_key != ck || f.sz.constraint_key != ck) return;
     if (A_.data().size() != 2 || !A_.has_key(ck, f.ls.var_key) || !A_.has_key(ck, f.sz.var_key))
@@ -547,6 +548,8 @@ class ProxADMMSolver final : public Solver {
     a.lam = f.sz.lam;
     a.sz_alpha = f.sz.alpha;
     a.sz_beta = f.sz.beta;
+    a.sz_alpha_vec = f.sz.alpha_vec;
+    a.sz_beta_vec = f.sz.beta_vec;
     a.sz_M = f.sz.M;
     a.u = f.u;
     a.x0 = f.x0;
@@ -884,6 +887,8 @@ class ProxADMMTwoBlockSolver final : public Solver {
     a.lam = f.sz.lam;
     a.sz_alpha = f.sz.alpha;
     a.sz_beta = f.sz.beta;
+    a.sz_alpha_vec = f.sz.alpha_vec;
+    a.sz_beta_vec = f.sz.beta_vec;
     a.sz_M = f.sz.M;
     a.chain = 1;
     a.u = f.u0;

@@ -57,6 +57,7 @@ struct LassoFusedArgs {
   double kappa = 0;                 // x0 = v0 + kappa * (A^T w)
   double Bs = 0, Cs = 0, a1 = 0;    // prox-1 pre / post scaling, y1 = a1 * x1
   double lam = 0, sz_alpha = 1, sz_beta = 1, sz_M = 0;
+  DVec sz_alpha_vec, sz_beta_vec;   // optional per-column alpha / beta (n entries; f32 pass only)
   DVec u, x0, x1, y0, y1, y1prev;   // n each, updated in place
   DVec tpart;                       // LassoFusedGrid(m, n) * m: per-workgroup partials of A v0'
   unsigned* epoch = nullptr;        // optional device counter, incremented once per launch

@@ -56,6 +56,8 @@ struct FusedScalars {
   float Bs, Cs, a1;
   float lam, alpha, beta, M;
   float a0, inv_aa;  // two-block form: constraint a0 x0 + a1 x1 = 0, 1 / (a0^2 + a1^2)
+  const float* alpha_v;  // per-column alpha / beta of the scaled zone (nullptr: the uniform values)
+  const float* beta_v;
 };
 
 // One column of the TWO-BLOCK driver's sweep (reference algorithms/prox_admm_two_block.cc:97-112):
@@ -422,10 +424,13 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
 #pragma unroll
     for (int wv2 = 4; wv2 < kBlock / 64; ++wv2) d += red[par][wv2];
     par ^= 1;
+    FusedScalars cj = c;
+    if (c.alpha_v != nullptr) cj.alpha = c.alpha_v[j];
+    if (c.beta_v != nullptr) cj.beta = c.beta_v[j];
     float v0n;
     if (MODE == 0) {
       float nx0, nx1, ny0, ny1, nu;
-      v0n = ChainOne(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
+      v0n = ChainOne(d, cj, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
       if (tid == 0) {
         y1prev[j] = y1j;
         x0[j] = nx0;
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernel(
       }
     } else {
       float nx0, nx1, nz0, nz1, nu0, nu1;
-      v0n = ChainTwoBlock(d, c, y0j, y1j, uj, u1j, &nx0, &nx1, &nz0, &nz1, &nu0, &nu1);
+      v0n = ChainTwoBlock(d, cj, y0j, y1j, uj, u1j, &nx0, &nx1, &nz0, &nz1, &nu0, &nu1);
       if (tid == 0) {
         y1prev[j] = y0j;  // z_prev
         e1[j] = y1j;
@@ -479,7 +484,7 @@ void LaunchFused(int grid, int64_t m, int64_t n, const float* A, int64_t lda, co
   // default: the streaming kernel (6.0 vs 5.75 TB/s on the 1e4 x 5e4 matrix); "pair" selects the
   // two-column form (256-thread workgroups only)
   static const char* env = std::getenv("EPSILON_HIP_FUSED_KERNEL");
-  const bool stream = !(env && env[0] == 'p') || BS != 256;
+  const bool stream = !(env && env[0] == 'p') || BS != 256 || c.alpha_v != nullptr || c.beta_v != nullptr;
   if (stream) {
     hipLaunchKernelGGL((LassoFusedStreamKernel<NR, BS, 0>), dim3(grid), dim3(BS), 0,
                        Runtime::Get().stream(), m, n, A, lda, w, c, u, x0, x1, y0, y1, y1prev,
@@ -667,6 +672,7 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == dt);
   if (dt == F64) {
     EPS_CHECK_MSG(a.chain == 0, "the two-block chain is f32 only");
+    EPS_CHECK_MSG(a.sz_alpha_vec.n == 0 && a.sz_beta_vec.n == 0, "per-column alpha / beta: f32 pass only");
     LassoFusedPassF64(a, grid, block);
     return;
   }
@@ -683,6 +689,16 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   c.M = static_cast<float>(a.sz_M);
   c.a0 = static_cast<float>(a.a0);
   c.inv_aa = static_cast<float>(1.0 / (a.a0 * a.a0 + a.a1 * a.a1));
+  c.alpha_v = c.beta_v = nullptr;
+  if (a.sz_alpha_vec.n > 0) {
+    EPS_CHECK(a.sz_alpha_vec.n == a.n && a.sz_alpha_vec.dt == F32);
+    c.alpha_v = a.sz_alpha_vec.as<float>();
+  }
+  if (a.sz_beta_vec.n > 0) {
+    EPS_CHECK(a.sz_beta_vec.n == a.n && a.sz_beta_vec.dt == F32);
+    c.beta_v = a.sz_beta_vec.as<float>();
+  }
+  // (the pair kernel has no per-column parameters: the streaming kernel is forced below)
   if (a.chain == 1) EPS_CHECK(a.e0.n == a.n && a.e1.n == a.n && a.e0.dt == F32 && a.e1.dt == F32);
   ProfScope prof("lasso_fused", a.m, a.n);
   const int64_t need = (a.m + 4 * block - 1) / (4 * block);  // float4 row chunks per thread

@@ -293,10 +293,12 @@ class ScaledZoneProx final : public VectorProx {
 
  public:
   bool DescribeScaledZone(ScaledZoneDesc* d) const override {
-    if (alpha_.is_vec || beta_.is_vec || has_axis_) return false;
+    if (has_axis_) return false;
     if (!ScalarForm(&d->var_key, &d->constraint_key, &d->Bs, &d->Cs, &d->lam)) return false;
     d->alpha = alpha_.value;
     d->beta = beta_.value;
+    d->alpha_vec = alpha_.is_vec ? alpha_.vec : DVec();
+    d->beta_vec = beta_.is_vec ? beta_.vec : DVec();
     d->M = M_;
     return true;
   }

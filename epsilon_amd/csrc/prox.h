@@ -47,6 +47,7 @@ struct ScaledZoneDesc {  // ScaledZoneProx with scalar H, A and uniform paramete
   std::string var_key, constraint_key;
   double Bs = 0, Cs = 0;  // v' = Bs*v ; x = Cs*x'
   double lam = 0, alpha = 1, beta = 1, M = 0;
+  DVec alpha_vec, beta_vec;  // per-element alpha / beta (SUM_QUANTILE with data vectors); empty: uniform
 };
 
 class ProxOperator {  // reference prox/prox.h:37-43

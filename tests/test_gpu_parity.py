@@ -638,7 +638,7 @@ def test_rccl_backend_single_rank(solve_mod):
 
 @pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (4100, 4301), (8, 21), (1500, 701),
                                    (10244, 10260)])   # past the 10240 rows that 256 threads hold
-@pytest.mark.parametrize("kind", ["lasso", "deadzone"])
+@pytest.mark.parametrize("kind", ["lasso", "deadzone", "quantile"])
 def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
     """The one-pass fused sweep (kernels_fused.hip) against the unfused operator path (same
     library, fused=0) and the oracle: same stopping sweep, same residuals, iterates within fp32
@@ -654,8 +654,16 @@ def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
         y = ir.variable(n, 1, problems.LASSO_VAR)
         f0 = ir.prox(ProxFunction.SUM_SQUARE, ir.add(ir.linear_map(ir.dense_matrix(A), x),
                                                      ir.linear_map(ir.scalar(-1, m), ir.constant(b))))
-        f1 = ir.prox(ProxFunction.SUM_DEADZONE, ir.linear_map(ir.scalar(2.0, n), y), alpha=lam,
-                     scaled_zone_params=wire.ProxScaledZoneParams(m=0.05))
+        if kind == "quantile":  # per-element alpha / beta from data vectors (scaled_zone.cc:34-76)
+            rq = np.random.RandomState(9)
+            qa, qb = ir.constant(0.2 + rq.rand(n)), ir.constant(0.2 + rq.rand(n))
+            qd = dict(qa.data)
+            qd.update(qb.data)
+            f1 = ir.prox(ProxFunction.SUM_QUANTILE, y, alpha=lam, data=qd,
+                         scaled_zone_params=wire.ProxScaledZoneParams(alpha_expr=qa.proto, beta_expr=qb.proto))
+        else:
+            f1 = ir.prox(ProxFunction.SUM_DEADZONE, ir.linear_map(ir.scalar(2.0, n), y), alpha=lam,
+                         scaled_zone_params=wire.ProxScaledZoneParams(m=0.05))
         prob = ir.Problem([f0, f1], [ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, n), y)))])
     pb, data = prob.SerializeToString(), prob.expression_data()
     sb = wire.SolverParams(max_iterations=200).SerializeToString()
@@ -686,7 +694,7 @@ def test_fused_sweep_matches_generic_and_oracle(solve_mod, shape, kind):
 
 
 @pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (8, 21), (4100, 4301)])
-@pytest.mark.parametrize("kind", ["lasso", "deadzone"])
+@pytest.mark.parametrize("kind", ["lasso", "deadzone", "quantile"])
 def test_fused_sweep_two_block_driver(solve_mod, shape, kind):
     """The same one-pass sweep for the TWO_BLOCK driver (prox_admm_two_block.cc:96-133): Jacobi
     x-updates, closed-form projection onto the consensus constraint, dual ascent - against the
@@ -702,8 +710,16 @@ def test_fused_sweep_two_block_driver(solve_mod, shape, kind):
         y = ir.variable(n, 1, problems.LASSO_VAR)
         f0 = ir.prox(ProxFunction.SUM_SQUARE, ir.add(ir.linear_map(ir.dense_matrix(A), x),
                                                      ir.linear_map(ir.scalar(-1, m), ir.constant(b))))
-        f1 = ir.prox(ProxFunction.SUM_DEADZONE, ir.linear_map(ir.scalar(2.0, n), y), alpha=lam,
-                     scaled_zone_params=wire.ProxScaledZoneParams(m=0.05))
+        if kind == "quantile":
+            rq = np.random.RandomState(9)
+            qa, qb = ir.constant(0.2 + rq.rand(n)), ir.constant(0.2 + rq.rand(n))
+            qd = dict(qa.data)
+            qd.update(qb.data)
+            f1 = ir.prox(ProxFunction.SUM_QUANTILE, y, alpha=lam, data=qd,
+                         scaled_zone_params=wire.ProxScaledZoneParams(alpha_expr=qa.proto, beta_expr=qb.proto))
+        else:
+            f1 = ir.prox(ProxFunction.SUM_DEADZONE, ir.linear_map(ir.scalar(2.0, n), y), alpha=lam,
+                         scaled_zone_params=wire.ProxScaledZoneParams(m=0.05))
         prob = ir.Problem([f0, f1], [ir.zero(ir.add(ir.linear_map(ir.scalar(2.0, n), x),
                                                    ir.linear_map(ir.scalar(-2.0, n), y)))])
     pb, data = prob.SerializeToString(), prob.expression_data()
