@@ -26,6 +26,7 @@ DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_gemv.hip", []),
                   ("kernels_gemv_multi.hip", []),
                   ("kernels_gemm.hip", []),
+                  ("kernels_gemm_f16split.hip", []),
                   ("kernels_factor.hip", []),
                   ("kernels_sparse.hip", []),
                   ("kernels_segprox.hip", ["-ffp-contract=off"]),

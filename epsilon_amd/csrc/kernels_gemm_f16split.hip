@@ -1,0 +1,327 @@
+// K4, long contractions: the Gram product A A^T on the f16 matrix cores with a two-term operand
+// split - fp32 accuracy at several times the fp32 MFMA rate.
+//
+// gfx950 runs v_mfma_f32_32x32x16_f16 at 16x the rate of the exact-f32 MFMA (2.5 PFLOP/s against
+// 157 TFLOP/s) and accumulates in f32.  An f32 value is split into two f16 terms,
+//       a * s_i = h + l ,   h = f16(a s_i),  l = f16(a s_i - h) ,
+// with one power-of-two scale s_i per ROW (max_k |a_ik| s_i in [1024, 2048): every row uses the
+// top of the f16 range whatever its norm).  h carries 11 bits of a s_i, l the next 11 (fewer only
+// for entries below 2^-13 of their row's maximum, whose l is subnormal: an absolute error of
+// 2^-25, i.e. 1e-11 of the row's scale): the pair represents a s_i to 2^-22 relative - two ulps
+// of f32 - and
+//       (a s_i)(b s_j) = h_a h_b + h_a l_b + l_a h_b + O(2^-22) ,
+// each of the three products exact in f32 (11 x 11 bits), all three into ONE f32 accumulator.
+// The error against exact arithmetic is that of an f32 GEMM whose inputs were perturbed by two
+// ulps - the order of the f32 MFMA's own accumulation rounding over K = 5e4 terms - at three
+// f16 MFMAs per f32 one: 3/16 of the matrix-core time.  The epilogue divides by s_i s_j (exact).
+//
+// The reference forms this product with dgemm_ (linear/linear_map_multiply.cc:14-37); it is the
+// one place the north star puts on the matrix cores, and 60 % of the time to OPTIMAL at config 2.
+//
+// Layout.  A (m x K, column-major f32) is converted once into two f16 arrays stored slab-major,
+// [K / 32][m_pad][32]: the 32 k-values of a row sit in 64 contiguous bytes, the rows of a tile in
+// 16 KB contiguous per slab - every global load of the product kernel is a full 16-byte lane load
+// of exactly what an MFMA fragment needs (8 consecutive k of one row).  Tile 256 x 256 per
+// 512-thread workgroup (8 waves as 2 x 4, each 128 x 64 = 4 x 2 blocks of 32 x 32), k slabs of 32,
+// operands staged through LDS (80-byte rows: conflict-free 16-byte fragment reads), the next
+// slab's global loads in flight while the current one multiplies.  Only tiles on and below the
+// diagonal are computed (compact 1-D grid); the caller mirrors.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace eps {
+namespace k {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TS = 256;       // tile rows / columns
+constexpr int SK = 32;        // k slab
+constexpr int LROW = 40;      // LDS row stride in halfs (80 bytes)
+constexpr int kThreads = 512;
+
+// ---- max_k |a_ik| per row (bit pattern of a non-negative float: integer order = float order) -------
+__global__ __launch_bounds__(256) void RowAbsMaxKernel(const float* __restrict__ A, int64_t M, int64_t K,
+                                                       int64_t lda, unsigned* __restrict__ rowmax_bits) {
+  const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+  if (i >= M) return;
+  const int64_t per = (K + gridDim.y - 1) / gridDim.y;
+  const int64_t k0 = blockIdx.y * per;
+  int64_t k1 = k0 + per;
+  if (k1 > K) k1 = K;
+  float mx = 0.0f;
+  const float* p = A + i;
+  int64_t k = k0;
+  for (; k + 4 <= k1; k += 4) {  // lanes run along the rows: every load is a coalesced 256-byte line
+    const float a = p[k * lda], b = p[(k + 1) * lda], c = p[(k + 2) * lda], d = p[(k + 3) * lda];
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(a), fabsf(b))), fmaxf(fabsf(c), fabsf(d)));
+  }
+  for (; k < k1; ++k) mx = fmaxf(mx, fabsf(p[k * lda]));
+  atomicMax(rowmax_bits + i, __float_as_uint(mx));
+}
+
+__device__ inline float SplitScale(unsigned amax_bits) {
+  const float amax = __uint_as_float(amax_bits);
+  if (!(amax > 0.0f) || !isfinite(amax)) return 1.0f;
+  int e;
+  frexpf(amax, &e);             // amax = f * 2^e, f in [0.5, 1)
+  return ldexpf(1.0f, 11 - e);  // amax * s in [1024, 2048)
+}
+
+// ---- f32 column-major -> two f16 arrays, slab-major [K/32][m_pad][32] ------------------------------
+// One workgroup converts a 64-row x 32-k block through an LDS transpose: reads are contiguous
+// along the rows (the matrix' storage order), writes are 16 bytes per lane along k.
+__global__ __launch_bounds__(256) void SplitConvertKernel(const float* __restrict__ A, int64_t M, int64_t K,
+                                                          int64_t lda, int64_t m_pad,
+                                                          const unsigned* __restrict__ rowmax_bits,
+                                                          _Float16* __restrict__ H, _Float16* __restrict__ L) {
+  __shared__ float tile[SK][65];
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * 64;
+  const int64_t ks = blockIdx.y;
+  const int t = threadIdx.x;
+  {
+    const int r = t & 63, kq = t >> 6;  // 4 k's per pass
+    const float s = i0 + r < M ? SplitScale(rowmax_bits[i0 + r]) : 1.0f;
+#pragma unroll
+    for (int p = 0; p < SK / 4; ++p) {
+      const int kk = kq + 4 * p;
+      const int64_t i = i0 + r, k = ks * SK + kk;
+      tile[kk][r] = (i < M && k < K) ? A[i + k * lda] * s : 0.0f;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = t >> 2, seg = t & 3;  // 64 rows x 4 segments of 8 k
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = tile[seg * 8 + j][r];
+      const _Float16 hv = static_cast<_Float16>(v);
+      h[j] = hv;
+      l[j] = static_cast<_Float16>(v - static_cast<float>(hv));
+    }
+    const int64_t off = ((ks * m_pad + i0 + r) * SK) + seg * 8;
+    if (i0 + r < m_pad) {
+      *reinterpret_cast<half8*>(H + off) = h;
+      *reinterpret_cast<half8*>(L + off) = l;
+    }
+  }
+}
+
+// ---- the product -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 2) void SyrkSplitF16Kernel(
+    int64_t M, int64_t nslab, int64_t m_pad, const _Float16* __restrict__ H, const _Float16* __restrict__ L,
+    const unsigned* __restrict__ rowmax_bits, float alpha, float beta, float* C, int64_t ldc, int64_t lin0,
+    int64_t slab0, int64_t slab_count, float* __restrict__ P) {
+  __shared__ __attribute__((aligned(16))) _Float16 sm[4][TS * LROW];  // H_I, L_I, H_J, L_J: 80 KB
+  // tile (I, J), I >= J, from the linear index over the lower triangle
+  const int64_t lin = lin0 + blockIdx.x;
+  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+  while (I * (I + 1) / 2 > lin) --I;
+  const int64_t J = lin - I * (I + 1) / 2;
+  const int64_t i0 = I * TS, j0 = J * TS;
+  // split-K form (tail tiles): blockIdx.y selects a run of slabs
+  int64_t ks0 = slab0, ks1 = slab0 + slab_count;
+  if (P != nullptr) {
+    ks0 = slab0 + static_cast<int64_t>(blockIdx.y) * slab_count;
+    ks1 = ks0 + slab_count;
+  }
+  if (ks1 > nslab) ks1 = nslab;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wi = wave & 1, wj = wave >> 1;  // 2 x 4 waves: rows wi*128, columns wj*64
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  // staging: a slab of one array and one side is 256 rows x 64 bytes = 1024 lane loads of 16 B,
+  // two per thread; q = t + 512 p -> row q >> 2, segment q & 3
+  half8 pre[4][2];
+  auto gload = [&](int64_t ks) {
+    const _Float16* hI = H + (ks * m_pad + i0) * SK;
+    const _Float16* lI = L + (ks * m_pad + i0) * SK;
+    const _Float16* hJ = H + (ks * m_pad + j0) * SK;
+    const _Float16* lJ = L + (ks * m_pad + j0) * SK;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int q = t + kThreads * p;
+      pre[0][p] = *reinterpret_cast<const half8*>(hI + q * 8);
+      pre[1][p] = *reinterpret_cast<const half8*>(lI + q * 8);
+      pre[2][p] = *reinterpret_cast<const half8*>(hJ + q * 8);
+      pre[3][p] = *reinterpret_cast<const half8*>(lJ + q * 8);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int q = t + kThreads * p;
+      const int off = (q >> 2) * LROW + (q & 3) * 8;
+#pragma unroll
+      for (int arr = 0; arr < 4; ++arr) *reinterpret_cast<half8*>(&sm[arr][off]) = pre[arr][p];
+    }
+  };
+  if (ks0 < ks1) gload(ks0);
+  for (int64_t ks = ks0; ks < ks1; ++ks) {
+    __syncthreads();  // the previous slab's fragment reads are done
+    lstore();
+    __syncthreads();
+    if (ks + 1 < ks1) gload(ks + 1);  // in flight under this slab's MFMAs
+#pragma unroll
+    for (int kk = 0; kk < SK; kk += 16) {
+      half8 ih[4], il[4], jh[2], jl[2];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int off = (wi * 128 + a * 32 + l31) * LROW + kk + 8 * lh;
+        ih[a] = *reinterpret_cast<const half8*>(&sm[0][off]);
+        il[a] = *reinterpret_cast<const half8*>(&sm[1][off]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int off = (wj * 64 + b * 32 + l31) * LROW + kk + 8 * lh;
+        jh[b] = *reinterpret_cast<const half8*>(&sm[2][off]);
+        jl[b] = *reinterpret_cast<const half8*>(&sm[3][off]);
+      }
+      // D'[j][i] += X_J[j][k] X_I[i][k]: the MFMA's "A" operand takes the J side, so a register's
+      // lanes run along i - consecutive rows of column-major C
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], ih[a], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], il[a], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jl[b], ih[a], acc[a][b], 0, 0, 0);
+        }
+    }
+  }
+
+  // undo the row scales: the accumulator holds s_i s_j (A A^T)_ij; 1 / s is a power of two
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int64_t i = i0 + wi * 128 + a * 32 + l31;
+    const float ui = (P == nullptr && i < M) ? 1.0f / SplitScale(rowmax_bits[i]) : 1.0f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (P != nullptr) {
+          P[(static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (TS * TS) + (i - i0) + (j - j0) * TS] =
+              acc[a][b][r];
+          continue;
+        }
+        if (i >= M || j >= M) continue;
+        float* c = C + i + j * ldc;
+        const float v = alpha * ((ui * (1.0f / SplitScale(rowmax_bits[j]))) * acc[a][b][r]);
+        *c = (beta == 0.0f) ? v : v + beta * (*c);
+      }
+    }
+  }
+}
+
+// tail tiles: C tile = alpha * (sum of the S partial tiles, in order) / (s_i s_j) + beta * C
+__global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64_t lin0, int S,
+                                                                const float* __restrict__ P,
+                                                                const unsigned* __restrict__ rowmax_bits,
+                                                                float alpha, float beta, float* C, int64_t ldc) {
+  const int64_t lin = lin0 + blockIdx.x;
+  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+  while (I * (I + 1) / 2 > lin) --I;
+  const int64_t i0 = I * TS, j0 = (lin - I * (I + 1) / 2) * TS;
+  const float* p0 = P + static_cast<int64_t>(blockIdx.x) * S * (TS * TS);
+  for (int e = threadIdx.x; e < TS * TS; e += 256) {
+    const int64_t i = i0 + (e & (TS - 1)), j = j0 + (e >> 8);
+    if (i >= M || j >= M) continue;
+    float sum = p0[e];
+    for (int c = 1; c < S; ++c) sum += p0[static_cast<int64_t>(c) * (TS * TS) + e];
+    float* dst = C + i + j * ldc;
+    const float unscale = (1.0f / SplitScale(rowmax_bits[i])) * (1.0f / SplitScale(rowmax_bits[j]));
+    const float v = alpha * (unscale * sum);
+    *dst = (beta == 0.0f) ? v : v + beta * (*dst);
+  }
+}
+
+}  // namespace
+
+bool SyrkSplitF16Wanted(int64_t M, int64_t K) {
+  static const bool off = [] {
+    const char* e = std::getenv("EPSILON_HIP_GRAM_F16SPLIT");
+    return e && e[0] == '0';
+  }();
+  // long contractions into large results only: below that the conversion and the 256-wide tiles
+  // do not pay, and the small parity cases keep the exact-f32 kernel (K >= 2048 admits the column
+  // slabs of an 8-way sharded config 2: 6250 columns per rank)
+  return !off && M >= 2048 && K >= 2048;
+}
+
+// C (lower tiles of M x M, ld ldc) = alpha * A A^T + beta * C for A = M x K column-major f32.
+void SyrkSplitF16(int64_t M, int64_t K, double alpha, const DVec& A, int64_t lda, double beta,
+                  const DVec& C, int64_t ldc) {
+  EPS_CHECK(A.dt == F32 && C.dt == F32 && lda >= M && ldc >= M);
+  EPS_CHECK(A.n >= (K - 1) * lda + M && C.n >= (M - 1) * ldc + M);
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  ProfScope prof("syrk_f16split", M * M, K);
+  const int64_t m_pad = (M + TS - 1) / TS * TS;
+  const int64_t nslab = (K + SK - 1) / SK;
+  auto hbuf = rt.Alloc(static_cast<size_t>(nslab) * m_pad * SK * sizeof(_Float16));
+  auto lbuf = rt.Alloc(static_cast<size_t>(nslab) * m_pad * SK * sizeof(_Float16));
+  auto mbuf = rt.Alloc(static_cast<size_t>(M) * sizeof(unsigned));
+  _Float16* H = static_cast<_Float16*>(hbuf->p);
+  _Float16* L = static_cast<_Float16*>(lbuf->p);
+  unsigned* amax = static_cast<unsigned*>(mbuf->p);  // per-row maxima (bit patterns)
+  EPS_HIP(hipMemsetAsync(amax, 0, static_cast<size_t>(M) * sizeof(unsigned), s));
+  {
+    const unsigned gx = static_cast<unsigned>((M + 255) / 256);
+    const unsigned gy = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(256, 2048 / gx)));
+    hipLaunchKernelGGL(RowAbsMaxKernel, dim3(gx, gy), dim3(256), 0, s, A.as<float>(), M, K, lda, amax);
+  }
+  hipLaunchKernelGGL(SplitConvertKernel, dim3(static_cast<unsigned>(m_pad / 64), static_cast<unsigned>(nslab)),
+                     dim3(256), 0, s, A.as<float>(), M, K, lda, m_pad, amax, H, L);
+  const int64_t T = m_pad / TS;
+  const int64_t total = T * (T + 1) / 2;
+  // one 512-thread workgroup per CU: rounds of 256 tiles; the ragged last round is split over K
+  const int64_t slots = 256;
+  int64_t tail = total % slots;
+  int S = 1;
+  int64_t per = nslab;
+  if (total > slots && tail > 0 && tail <= slots / 2) {
+    S = static_cast<int>(std::min<int64_t>(8, slots / tail));
+    per = (nslab + S - 1) / S;
+    S = static_cast<int>((nslab + per - 1) / per);
+  } else {
+    tail = 0;
+  }
+  const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
+  const int64_t full = total - tail;
+  if (full > 0)
+    hipLaunchKernelGGL(SyrkSplitF16Kernel, dim3(static_cast<unsigned>(full)), dim3(kThreads), 0, s, M, nslab,
+                       m_pad, H, L, amax, al, be, C.as<float>(), ldc, static_cast<int64_t>(0),
+                       static_cast<int64_t>(0), nslab, static_cast<float*>(nullptr));
+  if (tail > 0) {
+    auto pbuf = rt.Alloc(static_cast<size_t>(tail) * S * TS * TS * sizeof(float));
+    float* P = static_cast<float*>(pbuf->p);
+    hipLaunchKernelGGL(SyrkSplitF16Kernel, dim3(static_cast<unsigned>(tail), static_cast<unsigned>(S)),
+                       dim3(kThreads), 0, s, M, nslab, m_pad, H, L, amax, al, be, C.as<float>(), ldc, full,
+                       static_cast<int64_t>(0), per, P);
+    hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail)), dim3(256), 0, s, M, full, S,
+                       P, amax, al, be, C.as<float>(), ldc);
+  }
+  EPS_HIP(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace eps

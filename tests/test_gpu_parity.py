@@ -236,6 +236,40 @@ def test_gemm_mfma_vs_oracle(solve_mod):
     assert np.array_equal(C, C.T)
 
 
+@pytest.mark.parametrize("shape", [(2300, 8200), (5700, 8200)])
+def test_gram_f16_split_vs_fp64(solve_mod, shape):
+    """The Gram product of a long contraction runs on the f16 matrix cores with two-term split
+    operands (kernels_gemm_f16split.hip): it has to be as accurate as an f32 product - compared
+    with numpy fp64 on rows of very different scale (one global scale for the split), against the
+    error the exact-f32 kernel makes on the same input.  The second shape has more tiles than CUs:
+    its tail tiles take the split-K path."""
+    m, k = shape
+    rng = np.random.RandomState(21)
+    A = rng.randn(m, k) / np.sqrt(k)
+    A *= np.exp(rng.uniform(-4, 4, size=(m, 1)))  # row norms over e^-4 .. e^4
+    A = A.astype(np.float32).astype(np.float64)
+    Am = ir.dense_matrix(A)
+    ref = A.dot(A.T)
+    scale = np.sqrt(np.outer(np.diag(ref), np.diag(ref)))  # |C_ij| <= scale_ij
+    solve_mod.set_option("dtype", "f32")
+    _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
+    err_split = np.abs(C - ref) / scale
+    assert np.array_equal(C, C.T)
+    solve_mod.set_option("gemm", "mfma")  # forces the exact-f32 MFMA kernel
+    try:
+        _, C32 = solve_mod.linear_map_binary("*", Am, Am, False, True)
+    finally:
+        solve_mod.set_option("gemm", "auto")
+    err_f32 = np.abs(C32 - ref) / scale
+    # Both accumulate K terms in f32 (one rounding per term: ~sqrt(K) ulps on a sum of squares), so
+    # both sit a few 1e-6 from fp64 on the Cauchy-Schwarz scale; the split must not be worse than
+    # the exact-f32 kernel by more than rounding noise.
+    bound = 4 * np.sqrt(k) * 2.0 ** -24
+    assert err_split.max() < bound and err_f32.max() < bound, (err_split.max(), err_f32.max(), bound)
+    assert err_split.max() <= 1.5 * err_f32.max() + 2e-7, (err_split.max(), err_f32.max())
+    assert np.sqrt(np.mean(err_split ** 2)) <= 1.5 * np.sqrt(np.mean(err_f32 ** 2)) + 2e-8
+
+
 def test_gemm_f64_mfma_vs_numpy(solve_mod):
     """Dense*Dense in fp64 on v_mfma_f64_16x16x4_f64 (opt-in kernel; its accumulator map is NOT the
     f32 one): all four transpose combinations, ragged edges, asymmetric operands, SYRK."""
