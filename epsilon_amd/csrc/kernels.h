@@ -102,12 +102,12 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                  double beta, const DVec& C, int64_t ldc, int64_t sC, int64_t batch,
                  bool lower_only = false, int64_t outer = 1, int64_t sA2 = 0, int64_t sB2 = 0);
 void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc);
-// The Gram product A A^T (lower tiles) of a long contraction on the f16 matrix cores with a
-// two-term operand split (kernels_gemm_f16split.hip): f32 accuracy at 3/16 of the f32 MFMA time.
-// Gemm routes there by itself (f32, same buffer on both sides, M >= 2048, K >= 8192).
-bool SyrkSplitF16Wanted(int64_t M, int64_t K);
-void SyrkSplitF16(int64_t M, int64_t K, double alpha, const DVec& A, int64_t lda, double beta,
-                  const DVec& C, int64_t ldc);
+// Large f32 products on the f16 matrix cores with two-term split operands
+// (kernels_gemm_f16split.hip): f32 accuracy at 3/16 of the f32 MFMA time.  Gemm routes there by
+// itself (f32, M, N >= 2048, K >= 256, >= 8e9 multiply-adds); false = not eligible, nothing done.
+bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A,
+                  int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C, int64_t ldc,
+                  bool lower_only);
 // C (M x N, ldc == M, N <= 16) = alpha op(A) B + beta C as a mat-vec with N right-hand sides
 // (kernels_gemv_multi.hip); false if the shape / alignment is not covered (nothing is done).
 bool MultiGemv(bool transA, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,

@@ -602,12 +602,11 @@ int GemmMode() {  // 0 auto, 1 generic, 2 mfma, 3 mfma without the pipelined ker
 void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
           const DVec& A, int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C,
           int64_t ldc, bool lower_only) {
-  // the Gram product of one buffer with a long contraction: f16 matrix cores, split operands
-  if (lower_only && !transA && transB && A.dt == F32 && A.data() == B.data() && lda == ldb && M == N &&
-      GemmMode() == 0 && SyrkSplitF16Wanted(M, K)) {
-    SyrkSplitF16(M, K, alpha, A, lda, beta, C, ldc);
+  // large f32 products (the Gram product, the GEMMs of the Cholesky inverse): f16 matrix cores
+  // with split operands
+  if (A.dt == F32 && GemmMode() == 0 &&
+      GemmSplitF16(transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only))
     return;
-  }
   // A long contraction into a small result (X^T R of the multiclass hinge: 784 x 10 out of
   // K = 60000) has a handful of output tiles, each looping over all of K on one workgroup - 7
   // workgroups on 256 CUs, 7.3 ms.  Split K over batches into partial results and add them in

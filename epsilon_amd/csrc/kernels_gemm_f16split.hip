@@ -114,18 +114,71 @@ __global__ __launch_bounds__(256) void SplitConvertKernel(const float* __restric
   }
 }
 
+// The same for an operand stored contiguously along k (X[k + r * ld]): one wave per row for the
+// maximum, 16-byte lane writes for the conversion.
+__global__ __launch_bounds__(256) void RowAbsMaxKKernel(const float* __restrict__ X, int64_t R, int64_t K,
+                                                        int64_t ld, unsigned* __restrict__ rowmax_bits) {
+  const int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = X + r * ld;
+  float mx = 0.0f;
+  for (int64_t k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(p[k]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+  if (lane == 0) rowmax_bits[r] = __float_as_uint(mx);
+}
+
+__global__ __launch_bounds__(256) void SplitConvertKKernel(const float* __restrict__ X, int64_t R, int64_t K,
+                                                           int64_t ld, int64_t r_pad,
+                                                           const unsigned* __restrict__ rowmax_bits,
+                                                           _Float16* __restrict__ H, _Float16* __restrict__ L) {
+  const int64_t r = blockIdx.x * 64ll + (threadIdx.x >> 2);
+  const int seg = threadIdx.x & 3;
+  const int64_t ks = blockIdx.y;
+  if (r >= r_pad) return;
+  half8 h, l;
+  const float s = r < R ? SplitScale(rowmax_bits[r]) : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t k = ks * SK + seg * 8 + j;
+    const float v = (r < R && k < K) ? X[k + r * ld] * s : 0.0f;
+    const _Float16 hv = static_cast<_Float16>(v);
+    h[j] = hv;
+    l[j] = static_cast<_Float16>(v - static_cast<float>(hv));
+  }
+  const int64_t off = ((ks * r_pad + r) * SK) + seg * 8;
+  *reinterpret_cast<half8*>(H + off) = h;
+  *reinterpret_cast<half8*>(L + off) = l;
+}
+
+// One converted operand: rows = the output index it contributes (i for op(A), j for op(B)).
+struct SplitOperand {
+  const _Float16* H;
+  const _Float16* L;
+  const unsigned* rowmax;  // per-row maxima (bit patterns) -> the row's power-of-two scale
+  int64_t rows_pad;
+};
+
 // ---- the product -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads, 2) void SyrkSplitF16Kernel(
-    int64_t M, int64_t nslab, int64_t m_pad, const _Float16* __restrict__ H, const _Float16* __restrict__ L,
-    const unsigned* __restrict__ rowmax_bits, float alpha, float beta, float* C, int64_t ldc, int64_t lin0,
-    int64_t slab0, int64_t slab_count, float* __restrict__ P) {
+// C (M x N) = alpha * X_a X_b^T + beta * C with X_a = op(A) (rows i), X_b = op(B)^T (rows j).
+// tri != 0: M == N and only the tiles on and below the diagonal (compact 1-D grid, lin0 offset).
+__global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
+    int64_t M, int64_t N, int64_t nslab, SplitOperand oa, SplitOperand ob, float alpha, float beta, float* C,
+    int64_t ldc, int tri, int64_t lin0, int64_t slab0, int64_t slab_count, float* __restrict__ P) {
   __shared__ __attribute__((aligned(16))) _Float16 sm[4][TS * LROW];  // H_I, L_I, H_J, L_J: 80 KB
-  // tile (I, J), I >= J, from the linear index over the lower triangle
   const int64_t lin = lin0 + blockIdx.x;
-  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
-  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
-  while (I * (I + 1) / 2 > lin) --I;
-  const int64_t J = lin - I * (I + 1) / 2;
+  int64_t I, J;
+  if (tri) {  // tile (I, J), I >= J, from the linear index over the lower triangle
+    I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+    while (I * (I + 1) / 2 > lin) --I;
+    J = lin - I * (I + 1) / 2;
+  } else {
+    const int64_t TI = (M + TS - 1) / TS;
+    I = lin % TI;
+    J = lin / TI;
+  }
   const int64_t i0 = I * TS, j0 = J * TS;
   // split-K form (tail tiles): blockIdx.y selects a run of slabs
   int64_t ks0 = slab0, ks1 = slab0 + slab_count;
@@ -151,10 +204,10 @@ __global__ __launch_bounds__(kThreads, 2) void SyrkSplitF16Kernel(
   // two per thread; q = t + 512 p -> row q >> 2, segment q & 3
   half8 pre[4][2];
   auto gload = [&](int64_t ks) {
-    const _Float16* hI = H + (ks * m_pad + i0) * SK;
-    const _Float16* lI = L + (ks * m_pad + i0) * SK;
-    const _Float16* hJ = H + (ks * m_pad + j0) * SK;
-    const _Float16* lJ = L + (ks * m_pad + j0) * SK;
+    const _Float16* hI = oa.H + (ks * oa.rows_pad + i0) * SK;
+    const _Float16* lI = oa.L + (ks * oa.rows_pad + i0) * SK;
+    const _Float16* hJ = ob.H + (ks * ob.rows_pad + j0) * SK;
+    const _Float16* lJ = ob.L + (ks * ob.rows_pad + j0) * SK;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int q = t + kThreads * p;
@@ -207,11 +260,11 @@ __global__ __launch_bounds__(kThreads, 2) void SyrkSplitF16Kernel(
     }
   }
 
-  // undo the row scales: the accumulator holds s_i s_j (A A^T)_ij; 1 / s is a power of two
+  // undo the row scales: the accumulator holds s_i s_j (X_a X_b^T)_ij; 1 / s is a power of two
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int64_t i = i0 + wi * 128 + a * 32 + l31;
-    const float ui = (P == nullptr && i < M) ? 1.0f / SplitScale(rowmax_bits[i]) : 1.0f;
+    const float ui = (P == nullptr && i < M) ? 1.0f / SplitScale(oa.rowmax[i]) : 1.0f;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
@@ -222,9 +275,9 @@ __global__ __launch_bounds__(kThreads, 2) void SyrkSplitF16Kernel(
               acc[a][b][r];
           continue;
         }
-        if (i >= M || j >= M) continue;
+        if (i >= M || j >= N) continue;
         float* c = C + i + j * ldc;
-        const float v = alpha * ((ui * (1.0f / SplitScale(rowmax_bits[j]))) * acc[a][b][r]);
+        const float v = alpha * ((ui * (1.0f / SplitScale(ob.rowmax[j]))) * acc[a][b][r]);
         *c = (beta == 0.0f) ? v : v + beta * (*c);
       }
     }
@@ -256,71 +309,113 @@ __global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64
 
 }  // namespace
 
-bool SyrkSplitF16Wanted(int64_t M, int64_t K) {
+namespace {
+
+struct ConvertedOperand {
+  std::shared_ptr<Buffer> h, l, mx;
+  SplitOperand op;
+};
+
+// X holds `rows` rows of K entries: element (r, k) at X[r + k * ld] (contig_r) or X[k + r * ld].
+ConvertedOperand ConvertOperand(const float* X, int64_t rows, int64_t K, int64_t ld, bool contig_r) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  ConvertedOperand c;
+  const int64_t r_pad = (rows + TS - 1) / TS * TS;
+  const int64_t nslab = (K + SK - 1) / SK;
+  c.h = rt.Alloc(static_cast<size_t>(nslab) * r_pad * SK * sizeof(_Float16));
+  c.l = rt.Alloc(static_cast<size_t>(nslab) * r_pad * SK * sizeof(_Float16));
+  c.mx = rt.Alloc(static_cast<size_t>(rows) * sizeof(unsigned));
+  _Float16* H = static_cast<_Float16*>(c.h->p);
+  _Float16* L = static_cast<_Float16*>(c.l->p);
+  unsigned* amax = static_cast<unsigned*>(c.mx->p);
+  if (contig_r) {
+    EPS_HIP(hipMemsetAsync(amax, 0, static_cast<size_t>(rows) * sizeof(unsigned), s));
+    const unsigned gx = static_cast<unsigned>((rows + 255) / 256);
+    const unsigned gy = static_cast<unsigned>(
+        std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(256, K), 2048 / gx)));
+    hipLaunchKernelGGL(RowAbsMaxKernel, dim3(gx, gy), dim3(256), 0, s, X, rows, K, ld, amax);
+    hipLaunchKernelGGL(SplitConvertKernel, dim3(static_cast<unsigned>(r_pad / 64), static_cast<unsigned>(nslab)),
+                       dim3(256), 0, s, X, rows, K, ld, r_pad, amax, H, L);
+  } else {
+    hipLaunchKernelGGL(RowAbsMaxKKernel, dim3(static_cast<unsigned>((rows + 3) / 4)), dim3(256), 0, s, X, rows, K,
+                       ld, amax);
+    hipLaunchKernelGGL(SplitConvertKKernel, dim3(static_cast<unsigned>(r_pad / 64), static_cast<unsigned>(nslab)),
+                       dim3(256), 0, s, X, rows, K, ld, r_pad, amax, H, L);
+  }
+  c.op = SplitOperand{H, L, amax, r_pad};
+  return c;
+}
+
+bool SplitEnabled() {
   static const bool off = [] {
     const char* e = std::getenv("EPSILON_HIP_GRAM_F16SPLIT");
     return e && e[0] == '0';
   }();
-  // long contractions into large results only: below that the conversion and the 256-wide tiles
-  // do not pay, and the small parity cases keep the exact-f32 kernel (K >= 2048 admits the column
-  // slabs of an 8-way sharded config 2: 6250 columns per rank)
-  return !off && M >= 2048 && K >= 2048;
+  return !off;
 }
 
-// C (lower tiles of M x M, ld ldc) = alpha * A A^T + beta * C for A = M x K column-major f32.
-void SyrkSplitF16(int64_t M, int64_t K, double alpha, const DVec& A, int64_t lda, double beta,
-                  const DVec& C, int64_t ldc) {
-  EPS_CHECK(A.dt == F32 && C.dt == F32 && lda >= M && ldc >= M);
-  EPS_CHECK(A.n >= (K - 1) * lda + M && C.n >= (M - 1) * ldc + M);
+}  // namespace
+
+// General product C = alpha op(A) op(B) + beta C on the split-f16 kernel (large f32 products:
+// the GEMMs of the blocked Cholesky inverse).  false: not eligible, nothing done.
+bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A,
+                  int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C, int64_t ldc,
+                  bool lower_only) {
+  if (!SplitEnabled() || A.dt != F32 || B.dt != F32 || C.dt != F32) return false;
+  if (M < 2048 || N < 2048 || K < 256 || static_cast<double>(M) * N * K < 8.0e9) return false;
+  if (lower_only && M != N) return false;
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
-  ProfScope prof("syrk_f16split", M * M, K);
-  const int64_t m_pad = (M + TS - 1) / TS * TS;
+  ProfScope prof(lower_only ? "syrk_f16split" : "gemm_f16split", M * N, K);
   const int64_t nslab = (K + SK - 1) / SK;
-  auto hbuf = rt.Alloc(static_cast<size_t>(nslab) * m_pad * SK * sizeof(_Float16));
-  auto lbuf = rt.Alloc(static_cast<size_t>(nslab) * m_pad * SK * sizeof(_Float16));
-  auto mbuf = rt.Alloc(static_cast<size_t>(M) * sizeof(unsigned));
-  _Float16* H = static_cast<_Float16*>(hbuf->p);
-  _Float16* L = static_cast<_Float16*>(lbuf->p);
-  unsigned* amax = static_cast<unsigned*>(mbuf->p);  // per-row maxima (bit patterns)
-  EPS_HIP(hipMemsetAsync(amax, 0, static_cast<size_t>(M) * sizeof(unsigned), s));
-  {
-    const unsigned gx = static_cast<unsigned>((M + 255) / 256);
-    const unsigned gy = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(256, 2048 / gx)));
-    hipLaunchKernelGGL(RowAbsMaxKernel, dim3(gx, gy), dim3(256), 0, s, A.as<float>(), M, K, lda, amax);
+  // op(A)(i, k): A[i + k lda] (not transposed: contiguous along the rows) or A[k + i lda]
+  ConvertedOperand ca = ConvertOperand(A.as<float>(), M, K, lda, !transA);
+  const bool same = A.data() == B.data() && lda == ldb && transA != transB && M == N;
+  ConvertedOperand cb;
+  // op(B)^T(j, k) = op(B)(k, j): B[k + j ldb] (not transposed: contiguous along k) or B[j + k ldb]
+  if (!same) cb = ConvertOperand(B.as<float>(), N, K, ldb, transB);
+  const SplitOperand& oa = ca.op;
+  const SplitOperand& ob = same ? ca.op : cb.op;
+  const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
+  const int64_t TI = (M + TS - 1) / TS, TJ = (N + TS - 1) / TS;
+  if (!lower_only) {
+    hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(TI * TJ)), dim3(kThreads), 0, s, M, N, nslab,
+                       oa, ob, al, be, C.as<float>(), ldc, 0, static_cast<int64_t>(0), static_cast<int64_t>(0),
+                       nslab, static_cast<float*>(nullptr));
+    EPS_HIP(hipGetLastError());
+    return true;
   }
-  hipLaunchKernelGGL(SplitConvertKernel, dim3(static_cast<unsigned>(m_pad / 64), static_cast<unsigned>(nslab)),
-                     dim3(256), 0, s, A.as<float>(), M, K, lda, m_pad, amax, H, L);
-  const int64_t T = m_pad / TS;
-  const int64_t total = T * (T + 1) / 2;
-  // one 512-thread workgroup per CU: rounds of 256 tiles; the ragged last round is split over K
+  const int64_t total = TI * (TI + 1) / 2;
+  // one 512-thread workgroup per CU: rounds of 256 tiles; a ragged last round of a LONG
+  // contraction is split over K
   const int64_t slots = 256;
   int64_t tail = total % slots;
   int S = 1;
   int64_t per = nslab;
-  if (total > slots && tail > 0 && tail <= slots / 2) {
+  if (same && nslab >= 64 && total > slots && tail > 0 && tail <= slots / 2) {
     S = static_cast<int>(std::min<int64_t>(8, slots / tail));
     per = (nslab + S - 1) / S;
     S = static_cast<int>((nslab + per - 1) / per);
   } else {
     tail = 0;
   }
-  const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
   const int64_t full = total - tail;
   if (full > 0)
-    hipLaunchKernelGGL(SyrkSplitF16Kernel, dim3(static_cast<unsigned>(full)), dim3(kThreads), 0, s, M, nslab,
-                       m_pad, H, L, amax, al, be, C.as<float>(), ldc, static_cast<int64_t>(0),
-                       static_cast<int64_t>(0), nslab, static_cast<float*>(nullptr));
+    hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(full)), dim3(kThreads), 0, s, M, N, nslab, oa,
+                       ob, al, be, C.as<float>(), ldc, 1, static_cast<int64_t>(0), static_cast<int64_t>(0), nslab,
+                       static_cast<float*>(nullptr));
   if (tail > 0) {
     auto pbuf = rt.Alloc(static_cast<size_t>(tail) * S * TS * TS * sizeof(float));
     float* P = static_cast<float*>(pbuf->p);
-    hipLaunchKernelGGL(SyrkSplitF16Kernel, dim3(static_cast<unsigned>(tail), static_cast<unsigned>(S)),
-                       dim3(kThreads), 0, s, M, nslab, m_pad, H, L, amax, al, be, C.as<float>(), ldc, full,
+    hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(tail), static_cast<unsigned>(S)),
+                       dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, 1, full,
                        static_cast<int64_t>(0), per, P);
     hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail)), dim3(256), 0, s, M, full, S,
-                       P, amax, al, be, C.as<float>(), ldc);
+                       P, oa.rowmax, al, be, C.as<float>(), ldc);
   }
   EPS_HIP(hipGetLastError());
+  return true;
 }
 
 }  // namespace k

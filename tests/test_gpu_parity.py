@@ -270,6 +270,40 @@ def test_gram_f16_split_vs_fp64(solve_mod, shape):
     assert np.sqrt(np.mean(err_split ** 2)) <= 1.5 * np.sqrt(np.mean(err_f32 ** 2)) + 2e-8
 
 
+def test_gemm_f16_split_general_and_inverse(solve_mod):
+    """The split-f16 kernel as a general product (two different operands, all transpose
+    combinations, ragged edges) against fp64 and against the exact-f32 kernel's error; and the
+    blocked Cholesky inverse, whose large GEMMs take this kernel, at n = 4200."""
+    solve_mod.set_option("dtype", "f32")
+    rng = np.random.RandomState(23)
+    m, k, n = 2310, 2050, 2200
+    for ta in (False, True):
+        for tb in (False, True):
+            A = rng.randn(*((k, m) if ta else (m, k))) * np.exp(rng.uniform(-3, 3, size=((1, m) if ta else (m, 1))))
+            B = rng.randn(*((n, k) if tb else (k, n))) * np.exp(rng.uniform(-3, 3, size=((n, 1) if tb else (1, n))))
+            A = A.astype(np.float32).astype(np.float64)
+            B = B.astype(np.float32).astype(np.float64)
+            oa, ob = (A.T if ta else A), (B.T if tb else B)
+            ref = oa.dot(ob)
+            scale = np.outer(np.linalg.norm(oa, axis=1), np.linalg.norm(ob, axis=0))
+            _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, tb)
+            solve_mod.set_option("gemm", "mfma")
+            try:
+                _, C32 = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, tb)
+            finally:
+                solve_mod.set_option("gemm", "auto")
+            e16, e32 = np.abs(C - ref) / scale, np.abs(C32 - ref) / scale
+            assert e16.max() < 4 * np.sqrt(k) * 2.0 ** -24, (ta, tb, e16.max())
+            assert e16.max() <= 1.5 * e32.max() + 2e-7, (ta, tb, e16.max(), e32.max())
+    nn = 4200
+    Q = rng.randn(nn, nn + 300) / np.sqrt(nn)
+    Mx = (np.eye(nn) + 2 * Q.dot(Q.T)).astype(np.float32).astype(np.float64)
+    W = solve_mod.linear_map_inverse(ir.dense_matrix(Mx))
+    resid = np.abs(W.dot(Mx) - np.eye(nn)).max()
+    assert resid < 2e-4, resid
+    assert np.abs(W - np.linalg.inv(Mx)).max() < 1e-5 * np.abs(np.linalg.inv(Mx)).max() + 1e-6
+
+
 def test_gemm_f64_mfma_vs_numpy(solve_mod):
     """Dense*Dense in fp64 on v_mfma_f64_16x16x4_f64 (opt-in kernel; its accumulator map is NOT the
     f32 one): all four transpose combinations, ragged edges, asymmetric operands, SYRK."""
