@@ -70,8 +70,10 @@ __device__ inline float SplitScale(unsigned amax_bits) {
   const float amax = __uint_as_float(amax_bits);
   if (!(amax > 0.0f) || !isfinite(amax)) return 1.0f;
   int e;
-  frexpf(amax, &e);             // amax = f * 2^e, f in [0.5, 1)
-  return ldexpf(1.0f, 11 - e);  // amax * s in [1024, 2048)
+  frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+  int se = 11 - e;   // amax * 2^se in [1024, 2048)
+  if (se > 120) se = 120;  // (rows of subnormal size: keep the scale itself representable)
+  return ldexpf(1.0f, se);
 }
 
 // ---- f32 column-major -> two f16 arrays, slab-major [K/32][m_pad][32] ------------------------------
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
         }
         if (i >= M || j >= N) continue;
         float* c = C + i + j * ldc;
-        const float v = alpha * ((ui * (1.0f / SplitScale(ob.rowmax[j]))) * acc[a][b][r]);
+        const float v = alpha * ((ui * acc[a][b][r]) * (1.0f / SplitScale(ob.rowmax[j])));
         *c = (beta == 0.0f) ? v : v + beta * (*c);
       }
     }
@@ -301,8 +303,7 @@ __global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64
     float sum = p0[e];
     for (int c = 1; c < S; ++c) sum += p0[static_cast<int64_t>(c) * (TS * TS) + e];
     float* dst = C + i + j * ldc;
-    const float unscale = (1.0f / SplitScale(rowmax_bits[i])) * (1.0f / SplitScale(rowmax_bits[j]));
-    const float v = alpha * (unscale * sum);
+    const float v = alpha * (((1.0f / SplitScale(rowmax_bits[i])) * sum) * (1.0f / SplitScale(rowmax_bits[j])));
     *dst = (beta == 0.0f) ? v : v + beta * (*dst);
   }
 }
