@@ -642,6 +642,99 @@ int eps_bench_prox(int kind, int64_t n, int iters, double* ms_avg) {
   });
 }
 
+int eps_bench_svd(int64_t m, int64_t n, int rank, int max_sweeps, double perturb, double* ms_cold,
+                  int* sweeps_cold, double* ms_warm, int* sweeps_warm, double* defects) {
+  return Guard([&] {
+    EPS_CHECK(m > 0 && n > 0 && ms_cold != nullptr);
+    const DType dt = ConfiguredDType();
+    Runtime& rt = Runtime::Get();
+    // the reference's robust-PCA generator (python/epopt/problems/robust_pca.py:5-22):
+    // rank-r part + 10 % sparse part of 10 * randn; a cheap host generator (sum of uniforms)
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto uni = [&] {
+      st ^= st << 13;
+      st ^= st >> 7;
+      st ^= st << 17;
+      return static_cast<double>(st >> 11) * (1.0 / 9007199254740992.0);
+    };
+    auto gauss = [&] { return (uni() + uni() + uni() + uni() - 2.0) * 1.7320508075688772; };
+    std::vector<double> h(static_cast<size_t>(m) * std::max<int64_t>(rank, 1));
+    for (auto& v : h) v = gauss();
+    DVec A = DVec::FromHost(h.data(), m * std::max<int64_t>(rank, 1), dt);
+    h.resize(static_cast<size_t>(n) * std::max<int64_t>(rank, 1));
+    for (auto& v : h) v = gauss();
+    DVec B = DVec::FromHost(h.data(), n * std::max<int64_t>(rank, 1), dt);
+    DVec Y = DVec::Empty(m * n, dt);
+    {
+      std::vector<float> sp(static_cast<size_t>(m) * n);
+      for (auto& v : sp) v = uni() < 0.1 ? static_cast<float>(10.0 * gauss()) : 0.0f;
+      std::vector<double> col(m);
+      // upload column by column through the fp64 staging the DVec helpers take
+      std::vector<double> all(sp.begin(), sp.end());
+      sp.clear();
+      sp.shrink_to_fit();
+      Y = DVec::FromHost(all.data(), m * n, dt);
+    }
+    if (rank > 0) k::Gemm(false, true, m, n, rank, 1.0, A, m, B, n, 1.0, Y, m);
+    auto timed = [&](const DVec& W, const DVec& V, bool warm, double* ms, int* sweeps) {
+      rt.Sync();
+      hipEvent_t a, b;
+      EPS_HIP(hipEventCreate(&a));
+      EPS_HIP(hipEventCreate(&b));
+      EPS_HIP(hipEventRecord(a, rt.stream()));
+      const int sw = k::JacobiSvd(W, m, n, V, max_sweeps, warm, false);
+      EPS_HIP(hipEventRecord(b, rt.stream()));
+      EPS_HIP(hipEventSynchronize(b));
+      float e = 0;
+      EPS_HIP(hipEventElapsedTime(&e, a, b));
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+      *ms = e;
+      if (sweeps) *sweeps = sw;
+    };
+    auto measure = [&](const DVec& Y0, const DVec& W, const DVec& V, double* out) {
+      // out[0] = ||V^T V - I||_F / sqrt(n), out[1] = ||W V^T - Y||_F / ||Y||_F,
+      // out[2] = ||offdiag(W^T W)||_F / ||diag(W^T W)||_F
+      DVec T = DVec::Empty(n * n, dt);
+      k::Gemm(true, false, n, n, n, 1.0, V, n, V, n, 0.0, T, n);
+      k::AddDiag(T, n, n, -1.0, nullptr);
+      rt.ResetSlots();
+      const int s0 = rt.NewSlot(), s1 = rt.NewSlot(), s2 = rt.NewSlot(), s3 = rt.NewSlot(), s4 = rt.NewSlot();
+      k::SumSq(T, rt.SlotPtr(s0), false);
+      DVec R = Y0.Clone();
+      k::Gemm(false, true, m, n, n, 1.0, W, m, V, n, -1.0, R, m);
+      k::SumSq(R, rt.SlotPtr(s1), false);
+      k::SumSq(Y0, rt.SlotPtr(s2), false);
+      k::Gemm(true, false, n, n, m, 1.0, W, m, W, m, 0.0, T, n);
+      k::SumSq(T, rt.SlotPtr(s3), false);
+      DVec sig = DVec::Empty(n, dt);
+      k::ColNorms(W, m, n, sig, false);
+      DVec sq = DVec::Empty(n, dt);
+      k::DiagMul(sq, 1.0, sig, sig, 0.0);
+      k::SumSq(sq, rt.SlotPtr(s4), false);
+      rt.FetchSlots();
+      out[0] = std::sqrt(rt.SlotValue(s0) / static_cast<double>(n));
+      out[1] = std::sqrt(rt.SlotValue(s1) / rt.SlotValue(s2));
+      const double all = rt.SlotValue(s3), diag = rt.SlotValue(s4);
+      out[2] = std::sqrt(std::max(0.0, all - diag) / diag);
+    };
+    DVec W = Y.Clone();
+    DVec V = DVec::Empty(n * n, dt);
+    timed(W, V, false, ms_cold, sweeps_cold);
+    if (defects) measure(Y, W, V, defects);
+    if (ms_warm != nullptr && perturb >= 0) {
+      // a nearby matrix, as the next ADMM sweep would present: Y2 = Y + perturb * (scaled fill)
+      DVec Y2 = Y.Clone();
+      DVec N = Synthetic(m * n, dt, 1.0);
+      k::Axpby(Y2, perturb, N, 1.0);
+      DVec W2 = DVec::Empty(m * n, dt);
+      k::Gemm(false, false, m, n, n, 1.0, Y2, m, V, n, 0.0, W2, m);
+      timed(W2, V, true, ms_warm, sweeps_warm);
+      if (defects) measure(Y2, W2, V, defects + 3);
+    }
+  });
+}
+
 int eps_tv1d(const double* v, size_t n, double lam, double* x) {
   return Guard([&] {
     const DType dt = ConfiguredDType();

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "comm.h"
@@ -450,6 +451,138 @@ __global__ __launch_bounds__(kBlock) void PairEigKernel(const T* __restrict__ G,
   }
 }
 
+// fp32 form of PairEigKernel, rebuilt around the latency of a rotation step (the kernel is a chain
+// of 63 dependent steps on one workgroup: at 2.1 us per step it was 131 us per launch, a third of a
+// block-Jacobi step once the products run on the matrix cores).  A lane owns 8 CONSECUTIVE rows of
+// its pair's two columns: two 16-byte LDS reads per column instead of eight scalar ones (column
+// stride 68 floats keeps them aligned), the eigenvector columns are fetched with them so their
+// latency hides behind the dot products, the 8-lane sums run on DPP row operations instead of
+// ds_bpermute, and the rotation is formed with v_rcp / v_rsq / v_sqrt (1 ulp) instead of the
+// correctly rounded division and square-root sequences.
+constexpr int kELd = 68;
+
+template <int CTRL> __device__ __forceinline__ float DppMove(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 8 lanes of a group (aligned to 8 within a row of 16)
+__device__ __forceinline__ float Sum8(float v) {
+  v += DppMove<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += DppMove<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += DppMove<0x141>(v);  // row_half_mirror: lane i <-> 7 - i of the 8
+  return v;
+}
+__device__ __forceinline__ float Dot4(const float4& a, const float4& b, float acc) {
+  acc = __builtin_fmaf(a.x, b.x, acc);
+  acc = __builtin_fmaf(a.y, b.y, acc);
+  acc = __builtin_fmaf(a.z, b.z, acc);
+  return __builtin_fmaf(a.w, b.w, acc);
+}
+__device__ __forceinline__ void Rot4(float4& x, float4& y, float c, float s) {
+  const float4 u = x, w = y;
+  x.x = __builtin_fmaf(c, u.x, -s * w.x);
+  x.y = __builtin_fmaf(c, u.y, -s * w.y);
+  x.z = __builtin_fmaf(c, u.z, -s * w.z);
+  x.w = __builtin_fmaf(c, u.w, -s * w.w);
+  y.x = __builtin_fmaf(s, u.x, c * w.x);
+  y.y = __builtin_fmaf(s, u.y, c * w.y);
+  y.z = __builtin_fmaf(s, u.z, c * w.z);
+  y.w = __builtin_fmaf(s, u.w, c * w.w);
+}
+
+__global__ __launch_bounds__(kBlock) void PairEigFastKernel(const float* __restrict__ G, int nsplit,
+                                                            int64_t split_stride, float* __restrict__ J,
+                                                            int inner_sweeps, float tol, float skip_below,
+                                                            unsigned int* offmax) {
+  __shared__ __attribute__((aligned(16))) float A[kJN * kELd];  // column-major, stride 68
+  __shared__ __attribute__((aligned(16))) float E[kJN * kELd];
+  __shared__ float wmax[kBlock / 64];
+  const int t = threadIdx.x;
+  const float* g = G + static_cast<int64_t>(blockIdx.x) * kJN * kJN;
+  for (int q4 = t; q4 < kJN * kJN / 4; q4 += kBlock) {
+    const int c = q4 >> 4, r = (q4 & 15) * 4;
+    float4 v = *reinterpret_cast<const float4*>(g + 4 * q4);
+    for (int sp = 1; sp < nsplit; ++sp) {
+      const float4 w = *reinterpret_cast<const float4*>(g + sp * split_stride + 4 * q4);
+      v.x += w.x;
+      v.y += w.y;
+      v.z += w.z;
+      v.w += w.w;
+    }
+    *reinterpret_cast<float4*>(&A[c * kELd + r]) = v;
+    float4 e = {0.f, 0.f, 0.f, 0.f};
+    if (c >= r && c < r + 4) (&e.x)[c - r] = 1.0f;
+    *reinterpret_cast<float4*>(&E[c * kELd + r]) = e;
+  }
+  __syncthreads();
+  float mx = 0.0f;
+  for (int idx = t; idx < kJN * kJN; idx += kBlock) {
+    const int r = idx & 63, c = idx >> 6;
+    if (r > c) {
+      const float d = A[r * kELd + r] * A[c * kELd + c];
+      if (d > 0.0f) mx = fmaxf(mx, fabsf(A[c * kELd + r]) * __builtin_amdgcn_rsqf(d));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if ((t & 63) == 0) wmax[t >> 6] = mx;
+  __syncthreads();
+  const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  if (t == 0) atomicMax(offmax, __float_as_uint(m4));
+  float* jj = J + static_cast<int64_t>(blockIdx.x) * kJN * kJN;
+  if (m4 <= skip_below) {  // already orthogonal to working accuracy: J = I (E holds it)
+    for (int q4 = t; q4 < kJN * kJN / 4; q4 += kBlock)
+      *reinterpret_cast<float4*>(jj + 4 * q4) = *reinterpret_cast<const float4*>(&E[(q4 >> 4) * kELd + (q4 & 15) * 4]);
+    return;
+  }
+  const int pair = t >> 3, r0 = (t & 7) * 8;
+  for (int sw = 0; sw < inner_sweeps; ++sw) {
+    for (int step = 0; step < kJN - 1; ++step) {
+      int pp = pair - 1 + step;  // player(pos) = pos == 0 ? 0 : 1 + (pos - 1 + step) mod 63
+      if (pp >= kJN - 1) pp -= kJN - 1;
+      const int p = pair == 0 ? 0 : 1 + pp;
+      int qq = kJN - 2 - pair + step;
+      if (qq >= kJN - 1) qq -= kJN - 1;
+      const int q = 1 + qq;
+      float4* ap = reinterpret_cast<float4*>(&A[p * kELd + r0]);
+      float4* aq = reinterpret_cast<float4*>(&A[q * kELd + r0]);
+      float4* ep = reinterpret_cast<float4*>(&E[p * kELd + r0]);
+      float4* eq = reinterpret_cast<float4*>(&E[q * kELd + r0]);
+      float4 x0 = ap[0], x1 = ap[1], y0 = aq[0], y1 = aq[1];
+      float4 u0 = ep[0], u1 = ep[1], w0 = eq[0], w1 = eq[1];
+      float a = Dot4(x1, x1, Dot4(x0, x0, 0.0f));
+      float b = Dot4(y1, y1, Dot4(y0, y0, 0.0f));
+      float gm = Dot4(x1, y1, Dot4(x0, y0, 0.0f));
+      a = Sum8(a);
+      b = Sum8(b);
+      gm = Sum8(gm);
+      if (fabsf(gm) > tol * (__builtin_amdgcn_sqrtf(a) * __builtin_amdgcn_sqrtf(b))) {
+        const float zeta = (b - a) * __builtin_amdgcn_rcpf(2.0f * gm);
+        const float den = fabsf(zeta) + __builtin_amdgcn_sqrtf(__builtin_fmaf(zeta, zeta, 1.0f));
+        const float tt = __builtin_copysignf(__builtin_amdgcn_rcpf(den), zeta);
+        const float c = __builtin_amdgcn_rsqf(__builtin_fmaf(tt, tt, 1.0f));
+        const float s = c * tt;
+        if (s != 0.0f) {
+          Rot4(x0, y0, c, s);
+          Rot4(x1, y1, c, s);
+          Rot4(u0, w0, c, s);
+          Rot4(u1, w1, c, s);
+          ap[0] = x0;
+          ap[1] = x1;
+          aq[0] = y0;
+          aq[1] = y1;
+          ep[0] = u0;
+          ep[1] = u1;
+          eq[0] = w0;
+          eq[1] = w1;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int q4 = t; q4 < kJN * kJN / 4; q4 += kBlock)
+    *reinterpret_cast<float4*>(jj + 4 * q4) = *reinterpret_cast<const float4*>(&E[(q4 >> 4) * kELd + (q4 & 15) * 4]);
+}
+
 // dst[:, dst_block[b]] = src[:, b] for column blocks of kJB columns (rows x nblocks*kJB)
 template <class T>
 __global__ __launch_bounds__(kBlock) void PermuteBlocksKernel(T* __restrict__ dst,
@@ -554,6 +687,179 @@ __global__ __launch_bounds__(kBlock) void PanelUpdateKernel(T* __restrict__ dst,
   }
 }
 
+// ---- the three kernels of a block-Jacobi step on the matrix cores (fp32) ----------------------------
+// The thread-per-row / 4x4-per-thread forms above are fp32 VALU code fed from LDS one scalar at a
+// time: measured at n = 10^4 (157 pairs per step) 512 us for the Grams and 372 us per update,
+// against ~65 us (Gram: 0.4 GB read) and ~130 us (update: 0.8 GB read + written) of HBM time.
+// v_mfma_f32_32x32x2_f32 is exact fp32 at the vector peak rate, needs ONE register per operand
+// and lane:
+//   Gram   G = P^T P: the contraction runs over rows, so ANY assignment of rows to MFMA k-slots
+//          is valid as long as both operands use the same one: a lane reads 16-byte pieces of
+//          its own column straight into operand registers.
+//   Update P J: operands swapped (D^T = J^T P^T) so that the accumulator holds 32 consecutive
+//          rows of one output column on 32 consecutive lanes: loads and stores are 128-byte
+//          runs of a column; the 64 x 64 rotation block lives in 64 registers per lane.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// partial Gram matrices: grid (nsplit, h); G[(split * h + pair)] = 64 x 64, both triangles.
+// The contraction runs over rows, so ANY assignment of rows to MFMA k-slots is valid as long as
+// both operands use the same one: lane (c = l & 31, kk = l >> 5) reads 16 consecutive bytes of
+// its OWN column (rows 8j + 4kk .. +3 of a 32-row block); a block's eight loads per lane cover
+// whole 128-byte lines of the 64 columns.  (Tried and dropped: staging 128-row tiles through LDS
+// so that global loads run along rows in 512-byte runs - 158 us per launch against 135: two
+// workgroups per CU and a barrier per stage leave the matrix pipe idle more than the better
+// load pattern returns.)  The pairs are walked from the last to the first: the update of the
+// previous step wrote the panels in ascending order, so the most recently written ones - the
+// ones still in the 256 MB Infinity Cache - are read first (a 1-2 % effect).
+__global__ __launch_bounds__(kBlock, 2) void PanelGramMfmaKernel(const float* __restrict__ W,
+                                                                 int64_t rows, int64_t chunk, int64_t h,
+                                                                 float* __restrict__ G) {
+  __shared__ float red[4][3][16][64];  // [wave][tile 00, 10, 11][register][lane]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c = lane & 31, kk = lane >> 5;
+  const int64_t pair = h - 1 - static_cast<int64_t>(blockIdx.y);
+  const int64_t split = blockIdx.x;
+  const float* col0 = W + (pair * kJN + c) * rows + split * chunk + 4 * kk;
+  const float* col1 = col0 + 32 * rows;
+  f32x16 a00 = {0}, a10 = {0}, a11 = {0};
+  const int64_t nblk = chunk / 32;  // the chunk is a multiple of 32 rows (zero-padded)
+  // two register buffers used alternately (no copies: a copy of the prefetched block would make
+  // the wave wait for it before the matrix instructions it was meant to hide behind)
+  float4 va0[4], va1[4], vb0[4], vb1[4];
+  auto load = [&](float4* x0, float4* x1, int64_t blk) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x0[j] = *reinterpret_cast<const float4*>(col0 + blk * 32 + 8 * j);
+      x1[j] = *reinterpret_cast<const float4*>(col1 + blk * 32 + 8 * j);
+    }
+  };
+  auto compute = [&](const float4* x0v, const float4* x1v, float on) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0[4] = {on * x0v[j].x, on * x0v[j].y, on * x0v[j].z, on * x0v[j].w};
+      const float x1[4] = {on * x1v[j].x, on * x1v[j].y, on * x1v[j].z, on * x1v[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], x0[e], a00, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], x0[e], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], x1[e], a11, 0, 0, 0);
+      }
+    }
+  };
+  // straight-line loop body: loads AND products are unconditional (block index clamped to the
+  // last block, a surplus block enters scaled by zero).  A load or a product under a branch
+  // lets the compiler sink the load next to its use / merge the wait counts of the two paths,
+  // and the wave then waits for the block it was meant to prefetch.
+  const int64_t last = nblk - 1;
+  auto clamp = [&](int64_t x) { return x < last ? x : last; };
+  int64_t b = wave;
+  load(va0, va1, clamp(b));
+  while (b < nblk) {
+    load(vb0, vb1, clamp(b + 4));
+    __builtin_amdgcn_sched_barrier(0);  // the scheduler would otherwise sink the loads to their uses
+    compute(va0, va1, 1.0f);
+    __builtin_amdgcn_sched_barrier(0);
+    b += 4;
+    load(va0, va1, clamp(b + 4));
+    __builtin_amdgcn_sched_barrier(0);
+    compute(vb0, vb1, b < nblk ? 1.0f : 0.0f);
+    __builtin_amdgcn_sched_barrier(0);
+    b += 4;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    red[wave][0][r][lane] = a00[r];
+    red[wave][1][r][lane] = a10[r];
+    red[wave][2][r][lane] = a11[r];
+  }
+  __syncthreads();
+  // D[row][col] of a tile: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* g = G + (split * h + pair) * kJN * kJN;  // column-major 64 x 64
+  for (int idx = t; idx < 3 * 16 * 64; idx += kBlock) {
+    const int tl = idx / 1024, r = (idx >> 6) & 15, l = idx & 63;
+    const float v = red[0][tl][r][l] + red[1][tl][r][l] + red[2][tl][r][l] + red[3][tl][r][l];
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) + (tl >= 1 ? 32 : 0);
+    const int col = (l & 31) + (tl == 2 ? 32 : 0);
+    g[col + row * kJN] = v;             // (row, col) through the symmetric position: lanes contiguous
+    if (tl == 1) g[row + col * kJN] = v;  // the mirror of the off-diagonal tile
+  }
+}
+
+// dst panels <- src pair * J (64 x 64), 32-row blocks; grid (ceil(rows / (32 * 4 * RB)), h)
+// (Tried: non-temporal loads / stores for the update of V, so that its 0.8 GB per step do not
+// push the panels of W out of the Infinity Cache before the next Gram launch re-reads them:
+// Gram 133 -> 122 us, but the non-temporal update itself 162 -> 172 us; dropped.)
+constexpr int kUpdRB = 4;  // row blocks per wave: the 64 registers of J are set up once per wave
+__global__ __launch_bounds__(kBlock, 2) void PanelUpdateMfmaKernel(float* __restrict__ dst,
+                                                                   const float* __restrict__ src,
+                                                                   int64_t rows,
+                                                                   const float* __restrict__ J,
+                                                                   const int32_t* __restrict__ dst_block) {
+  __shared__ float Js[kJN * kJLd];  // [c][k], stride 65
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, kk = lane >> 5;
+  const int64_t pair = blockIdx.y;
+  const float* jg = J + pair * kJN * kJN;  // column-major: J[k + 64 c]
+  for (int idx = t; idx < kJN * kJN; idx += kBlock) Js[(idx >> 6) * kJLd + (idx & 63)] = jg[idx];
+  __syncthreads();
+  const int64_t nblk = rows / 32;
+  int64_t b = (static_cast<int64_t>(blockIdx.x) * 4 + wave) * kUpdRB;
+  if (b >= nblk) return;
+  float jf[2][32];  // A-slot operand: J[2 s + kk][32 t + r]
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int s = 0; s < 32; ++s) jf[tt][s] = Js[(32 * tt + r) * kJLd + 2 * s + kk];
+  // uniform bases + one 32-bit lane offset: every access is "scalar base + lane offset", which
+  // keeps the 64 addresses of a block out of the vector registers (a pair is 64 * rows floats,
+  // far below 2^32 bytes)
+  const float* sbase = src + pair * kJN * rows;
+  float* dbase0 = dst + static_cast<int64_t>(dst_block[2 * pair]) * kJB * rows;
+  float* dbase1 = dst + static_cast<int64_t>(dst_block[2 * pair + 1]) * kJB * rows;
+  const unsigned urows = static_cast<unsigned>(rows);
+  const unsigned lin = static_cast<unsigned>(r) + static_cast<unsigned>(kk) * urows;       // loads
+  const unsigned lout = static_cast<unsigned>(r) + static_cast<unsigned>(4 * kk) * urows;  // stores
+  const int64_t bend = b + kUpdRB < nblk ? b + kUpdRB : nblk;
+  float pa[32], pb[32];
+  auto load = [&](float* x, int64_t blk) {
+    const unsigned off = lin + static_cast<unsigned>(blk) * 32u;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) x[s] = (sbase + static_cast<int64_t>(2 * s) * rows)[off];
+  };
+  auto compute = [&](const float* x, int64_t blk, bool store) {
+    f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(jf[0][s], x[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(jf[1][s], x[s], acc1, 0, 0, 0);
+    }
+    // acc[reg] on lane l = out[row 32 blk + (l & 31)][column (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)]
+    if (!store) return;
+    const unsigned off = lout + static_cast<unsigned>(blk) * 32u;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int64_t cbase = static_cast<int64_t>((g & 3) + 8 * (g >> 2)) * rows;
+      (dbase0 + cbase)[off] = acc0[g];
+      (dbase1 + cbase)[off] = acc1[g];
+    }
+  };
+  const int64_t last = nblk - 1;  // unconditional, clamped loads (see PanelGramMfmaKernel)
+  auto clamp = [&](int64_t x) { return x < last ? x : last; };
+  load(pa, b);
+  while (b < bend) {
+    load(pb, clamp(b + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    compute(pa, b, true);
+    __builtin_amdgcn_sched_barrier(0);
+    ++b;
+    load(pa, clamp(b + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    compute(pb, b, b < bend);  // the products run either way, only the stores are conditional
+    __builtin_amdgcn_sched_barrier(0);
+    ++b;
+  }
+}
+
 // dst (rows_out x ncols, ld rows_out) column j = src (ld lds) column col[j], first rows_out rows
 template <class T>
 __global__ __launch_bounds__(kBlock) void GatherColsKernel(T* __restrict__ dst, int64_t rows_out,
@@ -565,12 +871,20 @@ __global__ __launch_bounds__(kBlock) void GatherColsKernel(T* __restrict__ dst, 
   for (int64_t i = threadIdx.x; i < rows_out; i += kBlock) d[i] = s[i];
 }
 
-template <class T>
+template <class T, bool kMfma = std::is_same<T, float>::value>
 int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, bool warm,
                     bool row_sharded) {
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   const DType dt = W.dt;
+  // fp32: Gram, rotation solve and update on the matrix-core / fast-rotation kernels
+  static const bool mfma_off = [] {
+    const char* e = std::getenv("EPSILON_HIP_SVD_MFMA");
+    return e && e[0] == '0';
+  }();
+  if constexpr (kMfma) {
+    if (mfma_off) return BlockJacobiImpl<T, false>(W, m, n, V, max_sweeps, warm, row_sharded);
+  }
   int64_t nb = (n + kJB - 1) / kJB;
   if (nb & 1) ++nb;
   const int64_t h = nb / 2, npad = nb * kJB;
@@ -585,7 +899,15 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
   Comm* comm = row_sharded ? rt.comm() : nullptr;
   const int64_t m_ref = comm ? static_cast<int64_t>(comm->AllReduceMaxHost(static_cast<double>(m)) + 0.5) : m;
   int64_t nsplit = 1;
-  while (nsplit < 8 && h * nsplit < 512 && m_ref / (nsplit * 2) >= 256) nsplit *= 2;
+  if constexpr (kMfma) {
+    // matrix-core Gram: a workgroup is four waves that each take every fourth 32-row block of the
+    // chunk; enough workgroups (~5 per CU) that the dispatcher evens out the CUs
+    static const char* ns_env = std::getenv("EPSILON_HIP_SVD_NSPLIT");  // tuning knob
+    const int64_t want = ns_env && std::atoi(ns_env) > 0 ? std::atoi(ns_env) : 512;
+    while (nsplit < 16 && h * nsplit < want && m_ref / (nsplit * 2) >= 256) nsplit *= 2;
+  } else {
+    while (nsplit < 8 && h * nsplit < 512 && m_ref / (nsplit * 2) >= 256) nsplit *= 2;
+  }
   const int64_t kchunk = ((m_ref + nsplit - 1) / nsplit + 31) / 32 * 32;
   const int64_t mp = nsplit * kchunk;
   // padded working copies
@@ -636,7 +958,11 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
     for (int64_t step = 0; step < steps; ++step) {
       // partial Grams in one launch: batch index = split * h + pair, split sp covers rows
       // [sp * kchunk, (sp + 1) * kchunk) of the panels (the last chunk is padded with zero rows)
-      if (mp >= 3072) {
+      if constexpr (kMfma) {
+        const dim3 gg(static_cast<unsigned>(nsplit), static_cast<unsigned>(h));
+        hipLaunchKernelGGL(PanelGramMfmaKernel, gg, dim3(kBlock), 0, s, Wp.as<float>(), mp, kchunk, h,
+                           G.as<float>());
+      } else if (mp >= 3072) {
         const dim3 gg(static_cast<unsigned>(nsplit), static_cast<unsigned>(h));
         hipLaunchKernelGGL(PanelGramKernel<T>, gg, dim3(kBlock), 0, s, Wp.as<T>(), mp, kchunk, h, G.as<T>());
       } else {
@@ -644,10 +970,25 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
                     kJN, kJN * kJN, h, false, nsplit, kchunk, kchunk);
       }
       if (comm) comm->AllReduceSum(G);
-      hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
-                         G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
-                         done_tol, offmax);
-      if (mp >= 3072) {
+      if constexpr (kMfma) {
+        hipLaunchKernelGGL(PairEigFastKernel, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
+                           G.as<float>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<float>(), inner,
+                           static_cast<float>(tol), static_cast<float>(done_tol), offmax);
+      } else {
+        hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
+                           G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
+                           done_tol, offmax);
+      }
+      if constexpr (kMfma) {
+        const dim3 gw(static_cast<unsigned>((mp / 32 + 4 * kUpdRB - 1) / (4 * kUpdRB)), static_cast<unsigned>(h));
+        hipLaunchKernelGGL(PanelUpdateMfmaKernel, gw, dim3(kBlock), 0, s, Wt.as<float>(), Wp.as<float>(), mp,
+                           J.as<float>(), dst_dev);
+        const dim3 gv(static_cast<unsigned>((npad / 32 + 4 * kUpdRB - 1) / (4 * kUpdRB)), static_cast<unsigned>(h));
+        hipLaunchKernelGGL(PanelUpdateMfmaKernel, gv, dim3(kBlock), 0, s, Vt.as<float>(), Vp.as<float>(), npad,
+                           J.as<float>(), dst_dev);
+        std::swap(Wp, Wt);
+        std::swap(Vp, Vt);
+      } else if (mp >= 3072) {
         // P <- P J with the panels' move folded in (Wt / Vt receive the new layout, then swap);
         // a thread per row needs thousands of rows to fill the chip (n = 2048: slower than the
         // batched GEMMs, n = 4096: 25 % faster per sweep)

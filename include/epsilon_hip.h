@@ -223,6 +223,15 @@ int eps_bench_spd_inverse_columns(int64_t n, int64_t cnt, int iters, double* ms_
  * prox/scaled_zone.cc:90-101, prox/non_negative.cc:8).  Algorithmic bytes 2 n s (3 n s for kind 1). */
 int eps_bench_prox(int kind, int64_t n, int iters, double* ms_avg);
 
+/* Microbenchmark of the singular value decomposition behind the orthogonally-invariant prox
+ * operators (reference prox/ortho_invariant.cc:36-50) on the reference's robust-PCA matrix
+ * (problems/robust_pca.py:5-22: rank-`rank` part + 10 % sparse part) of the configured dtype:
+ * milliseconds and Jacobi sweeps of a cold decomposition and of a warm-started one of a matrix
+ * `perturb` away (perturb < 0: skipped).  defects (6 doubles, may be NULL), cold then warm:
+ * ||V^T V - I||_F / sqrt(n), ||W V^T - Y||_F / ||Y||_F, ||offdiag(W^T W)||_F / ||diag(W^T W)||_F. */
+int eps_bench_svd(int64_t m, int64_t n, int rank, int max_sweeps, double perturb, double* ms_cold,
+                  int* sweeps_cold, double* ms_warm, int* sweeps_warm, double* defects);
+
 /* Exact 1-D total-variation prox of v (n float64) with weight lam
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
 int eps_tv1d(const double* v, size_t n, double lam, double* x);

@@ -65,12 +65,32 @@ def prox(kind, n=10 ** 8, iters=20, dtype="f32"):
                                          arrays * n * sz / ms.value / 1e6 / 8000.0), flush=True)
 
 
+def svd(n, m=None, rank=10, max_sweeps=40, perturb=1e-3, dtype="f32"):
+    """SVD behind the nuclear-norm prox on the reference's robust-PCA matrix (ortho_invariant.cc:36-50)"""
+    m = m or n
+    _solve.set_option("dtype", dtype)
+    ms_c, ms_w = ctypes.c_double(), ctypes.c_double()
+    sw_c, sw_w = ctypes.c_int(), ctypes.c_int()
+    d = (ctypes.c_double * 6)()
+    _solve._check(L.eps_bench_svd(ctypes.c_int64(m), ctypes.c_int64(n), ctypes.c_int(rank), ctypes.c_int(max_sweeps),
+                                  ctypes.c_double(perturb), ctypes.byref(ms_c), ctypes.byref(sw_c),
+                                  ctypes.byref(ms_w), ctypes.byref(sw_w), d))
+    print('{"kernel": "JacobiSvd", "m": %d, "n": %d, "dtype": "%s", "cold_ms": %.1f, "cold_sweeps": %d, '
+          '"warm_ms": %.1f, "warm_sweeps": %d, "perturb": %g, "cold_defects": [%.2e, %.2e, %.2e], '
+          '"warm_defects": [%.2e, %.2e, %.2e]}' % (m, n, dtype, ms_c.value, sw_c.value, ms_w.value, sw_w.value,
+                                                   perturb, d[0], d[1], d[2], d[3], d[4], d[5]), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemv", "gemm", "inverse"]
     if "prox" in what:
         for dt in ("f32", "f64"):
             for kind in (0, 1, 2):
                 prox(kind, dtype=dt)
+    for w in what:
+        if w.startswith("svd"):  # svd:<n>[:<max_sweeps>]
+            parts = w.split(":")
+            svd(int(parts[1]) if len(parts) > 1 else 4096, max_sweeps=int(parts[2]) if len(parts) > 2 else 40)
     if "gemv" in what:
         gemv(0, 10000, 50000)
         gemv(1, 10000, 50000)
