@@ -88,9 +88,10 @@ if __name__ == "__main__":
             for kind in (0, 1, 2):
                 prox(kind, dtype=dt)
     for w in what:
-        if w.startswith("svd"):  # svd:<n>[:<max_sweeps>]
+        if w.startswith("svd"):  # svd:<n>[:<max_sweeps>[:<rank>]]
             parts = w.split(":")
-            svd(int(parts[1]) if len(parts) > 1 else 4096, max_sweeps=int(parts[2]) if len(parts) > 2 else 40)
+            svd(int(parts[1]) if len(parts) > 1 else 4096, max_sweeps=int(parts[2]) if len(parts) > 2 else 40,
+                rank=int(parts[3]) if len(parts) > 3 else 10)
     if "gemv" in what:
         gemv(0, 10000, 50000)
         gemv(1, 10000, 50000)
