@@ -1,5 +1,6 @@
 #include "block.h"
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <sstream>
@@ -392,68 +393,82 @@ void BlockMatrix::Remove(const std::string& row, const std::string& col) {
 static const uint64_t kFillMax = std::numeric_limits<uint64_t>::max();
 static const uint64_t kFillForbidden = kFillMax - 1;  // sharded solve: would couple ranks
 
-uint64_t ComputeFill(const BlockMatrix& A, const std::string& k) {  // :11-48
-  std::set<std::string> keys;
-  bool has_diagonal = false;
-  for (const auto& it : A.col(k)) {
-    if (k == it.first) has_diagonal = true;
-    else keys.insert(it.first);
-  }
-  if (!has_diagonal) return kFillMax;
+// Upper bound on the non-zeros that eliminating column k adds to the remaining matrix: the
+// update is V D^-1 V^T with V the off-diagonal part of column k, so every ordered pair (i, j)
+// of its row keys contributes a block whose type follows from the multiply table and whose
+// size is rows(i) x rows(j) (the model of reference block_cholesky.cc:11-48; its own test
+// expects 4 and 25 for the two keys of block_cholesky_test.cc:69-70).
+uint64_t ComputeFill(const BlockMatrix& A, const std::string& k) {
+  struct Neighbour {
+    const std::string* key;
+    ImplType type;       // type of A(i, k)
+    ImplType times_pivot;  // type of A(i, k) * A(k, k)
+    uint64_t rows;
+  };
+  const auto& column = A.col(k);
+  const auto pivot = column.find(k);
+  if (pivot == column.end()) return kFillMax;  // nothing to divide by
+  const ImplType pivot_type = pivot->second.impl().type();
   const ShardSpec& sh = ShardSpec::Get();
   const bool sharded_solve = sh.active();
-  uint64_t fill = 0;
-  for (const std::string& i : keys) {
-    ImplType aik = ComputeType(A(i, k).impl().type(), A(k, k).impl().type());
-    for (const std::string& j : keys) {
-      ImplType type = ComputeType(aik, A(j, k).impl().type());
-      // Sharded solve: each rank holds its own slice of every sharded key, and all maps between
-      // sharded keys are block-local by construction of the per-rank problem.  Eliminating a
-      // REPLICATED key k would connect the slices of two sharded keys through it (a coupling
-      // across ranks that no rank can form locally, e.g. A_g^T A_h), so that order is refused;
-      // it also keeps the local slice sizes from steering the order away from the single-GPU one.
-      if (sharded_solve && !sh.IsSharded(k) && sh.IsSharded(i) && sh.IsSharded(j))
-        return kFillForbidden;
-      uint64_t mi = A(i, k).impl().m(), mj = A(j, k).impl().m();
-      if (sharded_solve) {  // sizes every rank agrees on
-        if (sh.IsSharded(i) && sh.global_dim(i)) mi = sh.global_dim(i);
-        if (sh.IsSharded(j) && sh.global_dim(j)) mj = sh.global_dim(j);
-      }
-      fill += Nonzeros(type, mi, mj);
+  std::vector<Neighbour> nb;
+  nb.reserve(column.size());
+  bool any_sharded = false;
+  for (const auto& entry : column) {
+    if (entry.first == k) continue;
+    Neighbour x;
+    x.key = &entry.first;
+    x.type = entry.second.impl().type();
+    x.times_pivot = ComputeType(x.type, pivot_type);
+    x.rows = static_cast<uint64_t>(entry.second.impl().m());
+    if (sharded_solve && sh.IsSharded(entry.first)) {
+      any_sharded = true;
+      if (sh.global_dim(entry.first)) x.rows = sh.global_dim(entry.first);  // sizes every rank agrees on
     }
+    nb.push_back(x);
   }
-  return fill;
+  // Sharded solve: each rank holds its own slice of every sharded key, and all maps between
+  // sharded keys are block-local by construction of the per-rank problem.  Eliminating a
+  // REPLICATED key k would connect the slices of two sharded keys through it (a coupling
+  // across ranks that no rank can form locally, e.g. A_g^T A_h), so that order is refused;
+  // it also keeps the local slice sizes from steering the order away from the single-GPU one.
+  if (sharded_solve && any_sharded && !sh.IsSharded(k)) return kFillForbidden;
+  uint64_t total = 0;
+  for (const Neighbour& left : nb)
+    for (const Neighbour& right : nb)
+      total += Nonzeros(ComputeType(left.times_pivot, right.type), left.rows, right.rows);
+  return total;
 }
 
-std::string NextKey(const BlockMatrix& A) {  // :51-64
-  std::string best_key;
-  uint64_t best_fill = kFillMax;
-  for (const std::string& key : A.col_keys()) {
-    uint64_t fill = ComputeFill(A, key);
-    if (fill < best_fill) {
-      best_key = key;
-      best_fill = fill;
-    }
-  }
-  EPS_CHECK_MSG(best_fill != kFillMax, "block LDL: no key with a diagonal block\n"
-                                           << A.DebugString());
-  EPS_CHECK_MSG(best_fill != kFillForbidden,
+// Greedy minimum-fill pivot: the first key, in column order, with the smallest bound (the
+// tie-break matters: it decides which of two equal candidates the solver eliminates first).
+std::string NextKey(const BlockMatrix& A) {
+  const std::set<std::string> key_set = A.col_keys();  // sorted: the order of the reference's loop
+  const std::vector<std::string> keys(key_set.begin(), key_set.end());
+  std::vector<uint64_t> bound(keys.size());
+  for (size_t c = 0; c < keys.size(); ++c) bound[c] = ComputeFill(A, keys[c]);
+  const auto best = std::min_element(bound.begin(), bound.end());
+  EPS_CHECK_MSG(best != bound.end() && *best != kFillMax, "block LDL: no key with a diagonal block\n"
+                                                              << A.DebugString());
+  EPS_CHECK_MSG(*best != kFillForbidden,
                 "sharded solve: every elimination order couples the sharded keys (shard by the "
                 "other dimension)\n" << A.DebugString());
-  return best_key;
+  return keys[static_cast<size_t>(best - bound.begin())];
 }
 
-static BlockMatrix RemoveKey(BlockMatrix* A, const std::string& key) {  // :68-83
+// Takes row and column `key` out of the symmetric matrix; returns the column without its
+// diagonal block (the V of the elimination step).
+static BlockMatrix DetachKey(BlockMatrix* A, const std::string& key) {
   BlockMatrix V;
-  std::vector<std::pair<std::string, std::string>> to_remove;
-  for (const auto& it : A->col(key)) {
-    to_remove.push_back(std::make_pair(it.first, key));
-    if (key != it.first) {
-      to_remove.push_back(std::make_pair(key, it.first));
-      V(it.first, key) = it.second;
-    }
+  std::vector<std::string> rows;
+  for (const auto& entry : A->col(key)) {
+    rows.push_back(entry.first);
+    if (entry.first != key) V(entry.first, key) = entry.second;
   }
-  for (const auto& rc : to_remove) A->Remove(rc.first, rc.second);
+  for (const std::string& r : rows) {
+    A->Remove(r, key);
+    if (r != key) A->Remove(key, r);
+  }
   return V;
 }
 
@@ -519,30 +534,29 @@ void RegisterGlobalDims(const BlockMatrix& A) {
 }
 }  // namespace
 
-void BlockCholesky::Compute(BlockMatrix A) {  // :119-133
+// Block LDL^T by successive elimination, A = L D L^T with unit block lower triangular L stored
+// as L - I (reference block_cholesky.cc:119-133): pick the pivot key, invert its diagonal
+// block, record the scaled column, subtract the Schur update from what is left.
+void BlockCholesky::Compute(BlockMatrix A) {
   RegisterGlobalDims(A);
-  const size_t n_cols = A.col_keys().size();
-  for (size_t i = 0; i < n_cols; ++i) {
-    std::string key = NextKey(A);
-    BlockMatrix Di_inv;
-    {
-      const ShardSpec& sh = ShardSpec::Get();
-      const LinearMap& Akk = A(key, key);
-      // a replicated block of a sharded solve is the same matrix on every rank (its sharded
-      // contributions were all-reduced): split the work of inverting a large dense one
-      if (sh.active() && (!sh.keys().empty() || !sh.local().empty()) && !sh.IsSharded(key) &&
-          Akk.impl().type() == DENSE_MATRIX) {
-        Di_inv(key, key) =
-            LinearMap(static_cast<const DenseMatrixImpl&>(Akk.impl()).InverseDistributed());
-      } else {
-        Di_inv(key, key) = Akk.Inverse();
-      }
-    }
-    BlockMatrix V = RemoveKey(&A, key);
-    L_ = L_ + V * Di_inv;
-    D_inv_ = D_inv_ + Di_inv;
-    A = A - V * Di_inv * V.Transpose();
-    p_.push_back(key);
+  const ShardSpec& sh = ShardSpec::Get();
+  for (size_t left = A.col_keys().size(); left > 0; --left) {
+    const std::string pivot = NextKey(A);
+    const LinearMap& block = A(pivot, pivot);
+    // a replicated block of a sharded solve is the same matrix on every rank (its sharded
+    // contributions were all-reduced): split the work of inverting a large dense one
+    const bool split_over_ranks = sh.active() && (!sh.keys().empty() || !sh.local().empty()) &&
+                                  !sh.IsSharded(pivot) && block.impl().type() == DENSE_MATRIX;
+    BlockMatrix Dinv;
+    Dinv(pivot, pivot) =
+        split_over_ranks ? LinearMap(static_cast<const DenseMatrixImpl&>(block.impl()).InverseDistributed())
+                         : block.Inverse();
+    const BlockMatrix V = DetachKey(&A, pivot);
+    const BlockMatrix column = V * Dinv;
+    A = A - column * V.Transpose();
+    L_ = L_ + column;
+    D_inv_ = D_inv_ + Dinv;
+    p_.push_back(pivot);
   }
   LT_ = L_.Transpose();
 }

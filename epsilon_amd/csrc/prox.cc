@@ -34,38 +34,46 @@ std::unique_ptr<ProxOperator> CreateProxOperator(int type, bool epigraph) {
 
 namespace {
 
-bool GetScalarBM(const BlockMatrix& A, double* alpha) {  // vector_prox.cc:4-26
-  bool first = true;
-  for (const auto& col : A.data()) {
-    if (col.second.size() != 1 || col.first != col.second.begin()->first) return false;
-    const LinearMap& Ai = col.second.begin()->second;
-    if (Ai.impl().type() != SCALAR_MATRIX) return false;
-    const double a = GetScalar(Ai);
-    if (first) {
-      *alpha = a;
-      first = false;
-    } else if (*alpha != a) {
-      return false;
-    }
+// What the argument map H and the constraint row A look like to an elementwise prox: the
+// diagonals of H^T H and of H A^T A H^T, provided both are block diagonal with one and the same
+// diagonal on every block (the test of reference vector_prox.cc:4-49).  `uniform` = every block
+// is a scalar multiple of the identity; then a single number stands for each diagonal.
+struct ArgScaling {
+  bool uniform = false;
+  std::vector<double> hth, haah;
+};
+
+// The common diagonal of a block-diagonal matrix whose blocks are scalar (scalar_only) or
+// scalar / diagonal maps; false when a block sits off the diagonal, has another type, or the
+// blocks disagree.
+bool CommonDiagonal(const BlockMatrix& M, bool scalar_only, std::vector<double>* out) {
+  out->clear();
+  bool have = false;
+  for (const auto& column : M.data()) {
+    const auto& rows = column.second;
+    if (rows.size() != 1 || rows.begin()->first != column.first) return false;
+    const LinearMap& blk = rows.begin()->second;
+    const ImplType ty = blk.impl().type();
+    if (ty != SCALAR_MATRIX && (scalar_only || ty != DIAGONAL_MATRIX)) return false;
+    std::vector<double> d = scalar_only ? std::vector<double>(1, GetScalar(blk)) : GetDiagonal(blk);
+    if (have && d != *out) return false;
+    if (!have) out->swap(d);
+    have = true;
   }
+  if (scalar_only && !have) out->assign(1, 0.0);  // (no blocks: the reference leaves the value unset)
   return true;
 }
 
-bool GetDiagonalBM(const BlockMatrix& A, std::vector<double>* alpha) {  // vector_prox.cc:28-49
-  bool first = true;
-  for (const auto& col : A.data()) {
-    if (col.second.size() != 1 || col.first != col.second.begin()->first) return false;
-    const LinearMap& Ai = col.second.begin()->second;
-    if (Ai.impl().type() != SCALAR_MATRIX && Ai.impl().type() != DIAGONAL_MATRIX) return false;
-    std::vector<double> a = GetDiagonal(Ai);
-    if (first) {
-      *alpha = a;
-      first = false;
-    } else if (*alpha != a) {
-      return false;
+bool DescribeScaling(const BlockMatrix& H, const BlockMatrix& A, ArgScaling* sc) {
+  const BlockMatrix Ht = H.Transpose();
+  const BlockMatrix HtH = Ht * H, HAAH = H * A.Transpose() * A * Ht;
+  for (const bool scalar_only : {true, false}) {
+    if (CommonDiagonal(HtH, scalar_only, &sc->hth) && CommonDiagonal(HAAH, scalar_only, &sc->haah)) {
+      sc->uniform = scalar_only;
+      return true;
     }
   }
-  return true;
+  return false;
 }
 
 }  // namespace
@@ -108,70 +116,57 @@ const DVec& VectorProxInput::value_vec(int i) const { return v_(affine::arg_key(
 
 void VectorProxOutput::set_value(int i, DVec x) { x_.Set(affine::arg_key(i), std::move(x)); }
 
-bool VectorProx::InitScalar(const ProxOperatorArg& arg) {  // vector_prox.cc:51-70
-  const double alpha = arg.prox_function().alpha;
+// With beta = diag(H^T H) and gamma = diag(H A^T A H^T) the update
+//   argmin_x f(Hx + g) + 1/2 ||Ax - v||^2
+// is an elementwise prox in the scaled variable: centre B v + g with B = H (beta / gamma) A^T,
+// weight lambda = alpha beta^2 / gamma, and the result mapped back by C = (1 / beta) H^T
+// (reference vector_prox.cc:51-138 derives the same three maps; uniform scalings keep them
+// scalar so that the sweep can recognise the structure, ScalarForm below).
+void VectorProx::Init(const ProxOperatorArg& arg) {
+  ArgScaling sc;
   const BlockMatrix& H = arg.affine_arg().A;
   const BlockMatrix& A = arg.affine_constraint().A;
-  BlockMatrix HT = H.Transpose();
-  BlockMatrix AT = A.Transpose();
-  double beta, gamma;
-  if (!GetScalarBM(HT * H, &beta) || !GetScalarBM(H * AT * A * HT, &gamma)) return false;
-  B_ = (beta / gamma) * H * AT;
-  C_ = (1 / beta) * HT;
-  D_ = BlockMatrix();
-  input_.lambda_ = alpha * beta * beta / gamma;
+  if (!DescribeScaling(H, A, &sc)) EPS_FATAL("Affine transformation is not scalar or diagonal");
+  const double alpha = arg.prox_function().alpha;
+  const BlockMatrix Ht = H.Transpose(), At = A.Transpose();
   input_.lambda_host_.clear();
   input_.lambda_dev_ = DVec();
-  input_.elementwise_ = false;
-  EPS_CHECK(input_.lambda_ >= 0);
-  return true;
-}
-
-bool VectorProx::InitDiagonal(const ProxOperatorArg& arg) {  // vector_prox.cc:72-118
-  const double alpha = arg.prox_function().alpha;
-  const BlockMatrix& H = arg.affine_arg().A;
-  const BlockMatrix& A = arg.affine_constraint().A;
-  BlockMatrix HT = H.Transpose();
-  BlockMatrix AT = A.Transpose();
-  std::vector<double> beta, gamma;
-  if (!GetDiagonalBM(HT * H, &beta) || !GetDiagonalBM(H * AT * A * HT, &gamma)) return false;
-  const size_t n = beta.size();
-  EPS_CHECK(gamma.size() == n);
-  std::vector<double> lambda(n), delta(n, 0.0), bq(n), binv(n);
-  for (size_t i = 0; i < n; ++i) {
-    if (gamma[i]) {
-      lambda[i] = alpha * beta[i] * beta[i] / gamma[i];
-    } else {  // zero weight: the variable is unconstrained by f, keep the prox centre
-      lambda[i] = 0;
-      beta[i] = 1;
-      gamma[i] = 1;
-      delta[i] = 1;
+  D_ = BlockMatrix();
+  if (sc.uniform) {
+    const double beta = sc.hth[0], gamma = sc.haah[0];
+    B_ = (beta / gamma) * H * At;
+    C_ = (1 / beta) * Ht;
+    input_.lambda_ = alpha * beta * beta / gamma;
+    input_.elementwise_ = false;
+    EPS_CHECK(input_.lambda_ >= 0);
+  } else {
+    // per-element weights.  An element that the constraint row does not see (gamma = 0) gets
+    // weight 0 and is passed through from v by the extra map D (its prox centre is kept).
+    const size_t n = sc.hth.size();
+    EPS_CHECK(sc.haah.size() == n);
+    std::vector<double> weight(n), centre(n), back(n), pass(n);
+    for (size_t e = 0; e < n; ++e) {
+      const bool seen = sc.haah[e] != 0;
+      const double be = seen ? sc.hth[e] : 1.0, ga = seen ? sc.haah[e] : 1.0;
+      weight[e] = seen ? alpha * be * be / ga : 0.0;
+      centre[e] = be / ga;
+      back[e] = 1 / be;
+      pass[e] = seen ? 0.0 : 1.0;
     }
-    bq[i] = beta[i] / gamma[i];
-    binv[i] = 1 / beta[i];
+    const DType dt = arg.data_map()->dtype();
+    auto on_columns = [&](const std::vector<double>& d) {  // the same diagonal on every column key of H
+      BlockMatrix M;
+      const LinearMap Dm = LinearMap::Diagonal(d, dt);
+      for (const std::string& key : H.col_keys()) M(key, key) = Dm;
+      return M;
+    };
+    B_ = H * on_columns(centre) * At;
+    C_ = on_columns(back) * Ht;
+    D_ = (At * A).Inverse() * on_columns(pass) * At;
+    input_.lambda_host_ = weight;
+    input_.lambda_dev_ = DVec::FromHost(weight.data(), static_cast<int64_t>(n), dt);
+    input_.elementwise_ = true;
   }
-  const DType dt = arg.data_map()->dtype();
-  LinearMap B0 = LinearMap::Diagonal(bq, dt);
-  LinearMap C0 = LinearMap::Diagonal(binv, dt);
-  LinearMap D0 = LinearMap::Diagonal(delta, dt);
-  BlockMatrix B_scale, C_scale, D_scale;
-  for (const std::string& key : H.col_keys()) {
-    B_scale(key, key) = B0;
-    C_scale(key, key) = C0;
-    D_scale(key, key) = D0;
-  }
-  B_ = H * B_scale * AT;
-  C_ = C_scale * HT;
-  D_ = (AT * A).Inverse() * D_scale * AT;
-  input_.lambda_host_ = lambda;
-  input_.lambda_dev_ = DVec::FromHost(lambda.data(), static_cast<int64_t>(n), dt);
-  input_.elementwise_ = true;
-  return true;
-}
-
-void VectorProx::Init(const ProxOperatorArg& arg) {  // vector_prox.cc:120-138
-  if (!InitScalar(arg) && !InitDiagonal(arg))
-    EPS_FATAL("Affine transformation is not scalar or diagonal");
   g_ = arg.affine_arg().b;
   input_.f_ = arg.prox_function();
 }

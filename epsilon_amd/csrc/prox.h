@@ -119,11 +119,6 @@ class VectorProx : public ProxOperator {
   // and handles the axis itself; elementwise operators are axis-agnostic.
   virtual void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) = 0;
 
- private:
-  bool InitScalar(const ProxOperatorArg& arg);
-  bool InitDiagonal(const ProxOperatorArg& arg);
-
- protected:
   // For DescribeScaledZone: true iff B_, C_ are single scalar blocks, no offset, scalar lambda.
   bool ScalarForm(std::string* var_key, std::string* constraint_key, double* Bs, double* Cs,
                   double* lam) const;
