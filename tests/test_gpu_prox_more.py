@@ -421,3 +421,28 @@ def test_symmetric_functions_block_jacobi(solve_mod, dtype, block_svd):
     dd = (d + np.sqrt(d * d + 4 * lam)) / 2
     want = (Q * dd) @ Q.T
     np.testing.assert_allclose(G, want, rtol=0, atol=(1e-8 if dtype == "f64" else 2e-3) * scale)
+
+
+@pytest.mark.parametrize("n", [96, 300, 700])
+def test_svd_factors_are_orthogonal_and_reconstruct(solve_mod, n):
+    """The decomposition behind the orthogonally-invariant operators on the reference's robust-PCA
+    matrix (problems/robust_pca.py:5-22: rank 10 + 10 % sparse part), through the library's
+    microbenchmark entry: on-chip kernel (n = 96) and block Jacobi on the matrix cores (fp32, every
+    larger size).  Y = W V^T with V orthogonal and W's columns orthogonal, cold and warm-started;
+    the defects are those of fp32 rotations accumulated over the sweeps (no Newton-Schulz clean-up
+    here, the prox operator adds that)."""
+    import ctypes
+    from epsilon_amd import _solve
+    solve_mod.set_option("dtype", "f32")
+    L = _solve.lib()
+    ms_c, ms_w = ctypes.c_double(), ctypes.c_double()
+    sw_c, sw_w = ctypes.c_int(), ctypes.c_int()
+    d = (ctypes.c_double * 6)()
+    _solve._check(L.eps_bench_svd(ctypes.c_int64(n), ctypes.c_int64(n), ctypes.c_int(10), ctypes.c_int(40),
+                                  ctypes.c_double(1e-3), ctypes.byref(ms_c), ctypes.byref(sw_c),
+                                  ctypes.byref(ms_w), ctypes.byref(sw_w), d))
+    assert 2 <= sw_c.value < 40 and 1 <= sw_w.value <= sw_c.value
+    for off in (0, 3):  # cold, warm
+        assert d[off + 0] < 2e-4, list(d)   # ||V^T V - I||_F / sqrt(n)
+        assert d[off + 1] < 2e-4, list(d)   # ||W V^T - Y||_F / ||Y||_F
+        assert d[off + 2] < 2e-3, list(d)   # off-diagonal mass of W^T W
