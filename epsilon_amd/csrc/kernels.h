@@ -14,6 +14,8 @@ namespace k {
 //  linear/diagonal_matrix_impl.h:23)
 void Fill(const DVec& y, double v);
 void Copy(const DVec& dst, const DVec& src);
+// y[i] = deterministic pseudo-random value in (-1, 1) (hash of seed and index)
+void FillHash(const DVec& y, uint64_t seed);
 // y = a*x + b*y   (b == 0 never reads y)
 void Axpby(const DVec& y, double a, const DVec& x, double b);
 // y = a * d .* x + b*y

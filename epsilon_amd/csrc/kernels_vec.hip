@@ -308,6 +308,28 @@ void Fill(const DVec& y, double v) {
   EPS_DISPATCH(y.dt, LaunchEw<T>(y.as<T>(), nullptr, nullptr, nullptr, y.n, FillF<T>{T(v)}));
 }
 
+namespace {
+// y[i] = a deterministic pseudo-random value in (-1, 1) (splitmix64 of seed and index): test
+// matrices for the randomized range finder of the thresholded SVD - any generic matrix will do
+template <class T> __global__ __launch_bounds__(256) void FillHashKernel(T* y, int64_t n, uint64_t seed) {
+  const int64_t i = blockIdx.x * static_cast<int64_t>(256) + threadIdx.x;
+  if (i >= n) return;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * static_cast<uint64_t>(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  y[i] = static_cast<T>(static_cast<double>(z >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+}
+}  // namespace
+
+void FillHash(const DVec& y, uint64_t seed) {
+  if (y.n == 0) return;
+  hipStream_t s = Runtime::Get().stream();
+  const unsigned grid = static_cast<unsigned>((y.n + 255) / 256);
+  if (y.dt == F32) hipLaunchKernelGGL(FillHashKernel<float>, dim3(grid), dim3(256), 0, s, y.as<float>(), y.n, seed);
+  else hipLaunchKernelGGL(FillHashKernel<double>, dim3(grid), dim3(256), 0, s, y.as<double>(), y.n, seed);
+}
+
 void Copy(const DVec& dst, const DVec& src) {
   CheckSame(dst, src);
   if (dst.n == 0 || dst.data() == src.data()) return;

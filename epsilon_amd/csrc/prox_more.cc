@@ -303,6 +303,10 @@ class OrthoInvariantProx : public VectorProx {
     calls_ = 0;
     const char* e = std::getenv("EPSILON_HIP_SVD_WARM");
     warm_start_ = !(e && e[0] == '0');
+    const char* pe = std::getenv("EPSILON_HIP_SVD_PARTIAL");
+    partial_enabled_ = !(pe && pe[0] == '0');
+    partial_backoff_ = 0;
+    last_rank_ = -1;
   }
 
  protected:
@@ -317,6 +321,21 @@ class OrthoInvariantProx : public VectorProx {
     const bool row_sharded = shard.active() && shard.IsSharded(affine::arg_key(0));
     EPS_CHECK_MSG(!(row_sharded && symmetric_part_),
                   "symmetric matrix functions are not available on a row-sharded argument");
+    // Nuclear-norm prox: only the singular values above lambda survive the nested soft threshold
+    // (ortho_invariant.cc:76-105), so when they are few the leading block is all that is needed.
+    if (eigen_prox_type_ == pb::ProxFunction::NORM_1 && !symmetric_part_ && !epigraph_ && !row_sharded &&
+        partial_enabled_ && std::min(m_, n_) >= kPartialMinSize) {
+      if (partial_backoff_ > 0) {
+        --partial_backoff_;
+      } else {
+        DVec X;
+        if (ThresholdedPartialSvd(y, input.lambda(), &X)) {
+          output->set_value(0, X);
+          return;
+        }
+        partial_backoff_ = 16;  // the spectrum is (numerically) full above lambda: stop trying for a while
+      }
+    }
     DVec W, R;
     double shift = 0;
     if (symmetric_part_) {
@@ -415,6 +434,152 @@ class OrthoInvariantProx : public VectorProx {
   }
 
  private:
+  // Columns of Q (rows x k) <- an orthonormal basis of their span (one-sided Jacobi on the k
+  // columns: Q = W V^T, the columns of W orthogonal; a numerically null column becomes zero).
+  static void Orthonormalise(const DVec& Q, int64_t rows, int64_t k) {
+    DVec V = DVec::Empty(k * k, Q.dt);
+    k::JacobiSvd(Q, rows, k, V, 40, false, false);
+    DVec sig = DVec::Empty(k, Q.dt), one = DVec::Full(k, 1.0, Q.dt);
+    k::ColNorms(Q, rows, k, sig, false);
+    k::ColScaleByRatio(Q, rows, k, sig, one);
+  }
+
+  // X = sum over sigma_i > tau of (sigma_i - tau) u_i v_i^T from the leading singular block of
+  // Y alone: randomized block subspace iteration on the GEMM kernels (range finder + two power
+  // steps), the small problem by the Jacobi SVD, and an a-posteriori certificate - the block
+  // reaches below tau with room to spare AND the remainder Y - U S V^T has spectral norm <= tau
+  // (power iteration).  false: the numerical rank above tau is large (or the certificate
+  // fails); the caller computes the full decomposition.
+  bool ThresholdedPartialSvd(const DVec& y, double tau, DVec* X) {
+    Runtime& rt = Runtime::Get();
+    const int64_t m = m_, n = n_, kmax = std::min<int64_t>(512, std::min(m, n) / 4);
+    const int64_t guard = 8;  // captured values that must lie below tau
+    int64_t k = last_rank_ >= 0 ? (last_rank_ + guard + 8 + 31) / 32 * 32 : 32;
+    k = std::min(std::max<int64_t>(k, 32), kmax);
+    ProfScope prof("partial_svd", m, n);
+    rt.ResetSlots();
+    const int fro_slot = rt.NewSlot();
+    k::SumSq(y, rt.SlotPtr(fro_slot), false);
+    rt.FetchSlots();
+    const double fro2 = rt.SlotValue(fro_slot);  // sum of all squared singular values
+    int power = 2;  // power steps of the range finder
+    // a singular pair above the threshold counts as converged when || Y v - sigma u || is at the
+    // rounding level of the decomposition the full route would deliver
+    const double res_tol = y.dt == F32 ? 2e-5 : 1e-10;
+    for (int attempt = 0;; ++attempt) {
+      // range finder with `power` power steps: Q = orth(Y (Y^T Y)^power Omega)
+      DVec Z = DVec::Empty(n * k, y.dt), Q = DVec::Empty(m * k, y.dt);
+      k::FillHash(Z, 0x5EEDull + static_cast<uint64_t>(attempt));
+      k::Gemm(false, false, m, k, n, 1.0, y, m, Z, n, 0.0, Q, m);
+      for (int it = 0; it < power; ++it) {
+        Orthonormalise(Q, m, k);
+        k::Gemm(true, false, n, k, m, 1.0, y, m, Q, m, 0.0, Z, n);
+        Orthonormalise(Z, n, k);
+        k::Gemm(false, false, m, k, n, 1.0, y, m, Z, n, 0.0, Q, m);
+      }
+      Orthonormalise(Q, m, k);
+      // B = Q^T Y; its SVD through B^T (n x k): B^T = Wb Vb^T, columns of Wb = sigma_i v_i
+      DVec Wb = DVec::Empty(n * k, y.dt), Vb = DVec::Empty(k * k, y.dt);
+      k::Gemm(true, false, n, k, m, 1.0, y, m, Q, m, 0.0, Wb, n);
+      k::JacobiSvd(Wb, n, k, Vb, 40, false, false);
+      DVec sig = DVec::Empty(k, y.dt);
+      k::ColNorms(Wb, n, k, sig, false);
+      const std::vector<double> sh = sig.ToHost();
+      int64_t above = 0;
+      for (double sv : sh) above += sv > tau ? 1 : 0;
+      const bool reaches_below = above + guard <= k;
+      if (!reaches_below) {
+        if (k >= kmax) return false;
+        // Give up early when the energy outside the block alone implies more values above tau
+        // than the largest block holds: every value outside is (about) at most the block's
+        // smallest one, so their count is at least (outside energy - what values <= tau could
+        // carry) / that bound squared.  (A wrong guess here only sends a matrix the block could
+        // have handled to the full decomposition.)
+        double inside = 0, smin = sh[0];
+        for (double sv : sh) {
+          inside += sv * sv;
+          smin = std::min(smin, sv);
+        }
+        const double outside = fro2 - inside - static_cast<double>(std::min(m, n) - k) * tau * tau;
+        if (smin > 0 && outside / (2.25 * smin * smin) > static_cast<double>(kmax)) return false;
+        k = std::min(kmax, std::max(2 * k, (above + guard + 31) / 32 * 32));
+        continue;
+      }
+      DVec U = DVec::Empty(m * k, y.dt);
+      k::Gemm(false, false, m, k, k, 1.0, Q, m, Vb, k, 0.0, U, m);  // left singular vectors of the block
+      {
+        // convergence of the pairs that matter: Wb_i = Y^T u_i holds by construction, the other
+        // half || Y v_i - sigma_i u_i || = || Y Wb_i - sigma_i^2 u_i || / sigma_i is measured
+        DVec T = DVec::Empty(m * k, y.dt), U2 = U.Clone();
+        k::Gemm(false, false, m, k, n, 1.0, y, m, Wb, n, 0.0, T, m);
+        DVec one = DVec::Full(k, 1.0, y.dt), sig2 = DVec::Empty(k, y.dt);
+        k::DiagMul(sig2, 1.0, sig, sig, 0.0);
+        k::ColScaleByRatio(U2, m, k, one, sig2);
+        k::Axpby(T, -1.0, U2, 1.0);
+        DVec rn = DVec::Empty(k, y.dt);
+        k::ColNorms(T, m, k, rn, false);
+        const std::vector<double> rh = rn.ToHost();
+        double smax = 0;
+        for (double sv : sh) smax = std::max(smax, sv);
+        bool converged = true;
+        for (int64_t i = 0; i < k; ++i)
+          if (sh[i] > 0.99 * tau && !(rh[i] / sh[i] <= res_tol * smax)) converged = false;
+        if (!converged) {
+          if (power < 6) {
+            power += 2;
+          } else if (k < kmax) {
+            k = std::min(kmax, 2 * k);
+            power = 2;
+          } else {
+            return false;
+          }
+          continue;
+        }
+      }
+      // certificate: || Y - U Wb^T ||_2 by power iteration on R^T R (R x = Y x - U (Wb^T x))
+      DVec v = DVec::Empty(n, y.dt), w = DVec::Empty(m, y.dt), z = DVec::Empty(n, y.dt), c = DVec::Empty(k, y.dt);
+      k::FillHash(v, 0xC0FFEEull);
+      double est = 0;
+      for (int it = 0; it < 24; ++it) {
+        rt.ResetSlots();
+        const int slot = rt.NewSlot();
+        k::SumSq(v, rt.SlotPtr(slot), false);
+        rt.FetchSlots();
+        const double nv = std::sqrt(rt.SlotValue(slot));
+        if (!(nv > 0)) break;
+        k::Axpby(v, 1.0 / nv, v, 0.0);
+        k::Gemv(false, m, n, 1.0, y, m, v, 0.0, w);   // w = Y v
+        k::Gemv(true, n, k, 1.0, Wb, n, v, 0.0, c);   // c = Wb^T v
+        k::Gemv(false, m, k, -1.0, U, m, c, 1.0, w);  // w -= U c
+        rt.ResetSlots();
+        const int s2 = rt.NewSlot();
+        k::SumSq(w, rt.SlotPtr(s2), false);
+        rt.FetchSlots();
+        est = std::sqrt(rt.SlotValue(s2));           // ||R v|| with ||v|| = 1: a lower bound, increasing
+        k::Gemv(true, m, n, 1.0, y, m, w, 0.0, z);    // z = Y^T w
+        k::Gemv(true, m, k, 1.0, U, m, w, 0.0, c);    // c = U^T w
+        k::Gemv(false, n, k, -1.0, Wb, n, c, 1.0, z); // z -= Wb c
+        std::swap(v, z);
+      }
+      if (!(est <= tau * (1.0 + 1e-3))) {
+        if (k >= kmax) return false;
+        k = std::min(kmax, 2 * k);
+        continue;
+      }
+      // X = U diag(max(sigma - tau, 0) / sigma) Wb^T
+      DVec shr = DVec::Full(k, -tau, y.dt);
+      k::Axpby(shr, 1.0, sig, 1.0);
+      DVec pos = DVec::Empty(k, y.dt);
+      k::MaxZero(pos, shr);
+      k::ColScaleByRatio(U, m, k, sig, pos);  // U[:, i] *= pos_i / sigma_i (0 where sigma_i = 0)
+      DVec Xo = DVec::Empty(m * n, y.dt);
+      k::Gemm(false, true, m, n, k, 1.0, U, m, Wb, n, 0.0, Xo, m);
+      *X = Xo;
+      last_rank_ = above;
+      return true;
+    }
+  }
+
   void InitEigenProx(double lambda) {  // ortho_invariant.cc:76-98
     // The reference sizes the nested prox with min(m, n) and feeds it n values (:36-50,:77); n is
     // the well-defined reading.
@@ -451,6 +616,11 @@ class OrthoInvariantProx : public VectorProx {
   DVec V_prev_;  // right singular vectors of the previous application (warm start)
   int64_t calls_ = 0;
   bool warm_start_ = true;
+  // thresholded partial SVD (nuclear-norm prox of a large matrix)
+  static constexpr int64_t kPartialMinSize = 512;
+  bool partial_enabled_ = true;
+  int partial_backoff_ = 0;   // applications left before the partial route is tried again
+  int64_t last_rank_ = -1;    // singular values above lambda at the last successful partial call
 };
 
 #define EPS_ORTHO_OPERATOR(NAME, ...)                         \

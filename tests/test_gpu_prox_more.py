@@ -446,3 +446,45 @@ def test_svd_factors_are_orthogonal_and_reconstruct(solve_mod, n):
         assert d[off + 0] < 2e-4, list(d)   # ||V^T V - I||_F / sqrt(n)
         assert d[off + 1] < 2e-4, list(d)   # ||W V^T - Y||_F / ||Y||_F
         assert d[off + 2] < 2e-3, list(d)   # off-diagonal mass of W^T W
+
+
+@pytest.mark.parametrize("case", ["low_rank_tall", "low_rank_wide", "many_above", "full_rank", "edge_at_threshold"])
+def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
+    """From 512 columns / rows the nuclear-norm prox first tries the leading singular block alone
+    (randomized subspace iteration + Jacobi on the small problem, certified by the residuals of
+    the pairs above the threshold and by the spectral norm of the remainder), and falls back to the
+    full decomposition when the spectrum above lambda is wide or does not separate
+    (reference prox/ortho_invariant.cc:76-105 thresholds every singular value the same way).
+    Tall, wide, 70 values above the threshold, a full-rank matrix (fallback) and a bulk edge that
+    sits right at the threshold - all against numpy's SVD."""
+    from epsilon_amd import _solve
+    rng = np.random.RandomState(11)
+    if case == "low_rank_tall":
+        m, n, r, noise, lam = 900, 600, 12, 0.01, 2.0
+    elif case == "low_rank_wide":
+        m, n, r, noise, lam = 560, 1100, 9, 0.01, 2.0
+    elif case == "many_above":
+        m, n, r, noise, lam = 800, 800, 70, 0.01, 2.0
+    elif case == "full_rank":
+        m, n, r, noise, lam = 640, 640, 5, 1.0, 3.0     # bulk up to ~50: everything above lambda
+    else:
+        m, n, r, noise, lam = 700, 640, 8, 0.05, 1.8    # bulk edge 0.05 (sqrt(700) + sqrt(640)) ~ 2.6
+    V = rng.randn(m, r) @ rng.randn(r, n) + noise * rng.randn(m, n)
+    X = ir.variable(m, n, "var:X")
+    e = ir.prox(ProxFunction.NORM_NUCLEAR, X)
+    fb = e.proto.SerializeToString()
+    _solve.profile_enable(True)
+    _solve.profile_reset()
+    got = solve_mod.eval_prox(fb, lam, e.data, {"var:X": V.reshape(-1, order="F").tobytes()})
+    tags = _solve.profile_dump()
+    _solve.profile_enable(False)
+    G = np.frombuffer(got["var:X"]).reshape((m, n), order="F")
+    U, sv, Vt = np.linalg.svd(V, full_matrices=False)
+    want = (U * np.maximum(sv - lam, 0)) @ Vt
+    tol = dict(rtol=0, atol=1e-8 * sv[0]) if dtype == "f64" else dict(rtol=0, atol=3e-4 * sv[0])
+    np.testing.assert_allclose(G, want, **tol)
+    # the partial route was entered in every case; the full decomposition ran only where it had to
+    names = list(tags)
+    assert any(t.startswith("partial_svd") for t in names), names
+    full = ("block_jacobi_svd:%dx%d" % (m, n)) in names or ("jacobi_svd:%dx%d" % (m, n)) in names
+    assert full == (case in ("full_rank", "edge_at_threshold")), (case, names)
