@@ -24,6 +24,11 @@
 // every lane of a group holds identical bits and control flow stays group-uniform.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
 #include "kernels.h"
 
 namespace eps {
@@ -763,6 +768,671 @@ __global__ __launch_bounds__(kBlock) void SegLseEpiKernel(T* x, T* tout, const T
   if (c.lane == 0) tout[c.seg] = static_cast<T>(s + lam);
 }
 
+// ---- one LONG slice on the whole chip ------------------------------------------------------------------
+// The kernels above give a slice to at most one workgroup; a single slice of 1e7 entries (the max
+// of a long vector, log-sum-exp over all samples) then runs on one CU - measured 99 ms (MAX) and
+// 272 ms (LOG_SUM_EXP) at n = 1e7.  For long slices the scalar iteration stays the same but every
+// reduction of it becomes ONE launch of the whole grid: each workgroup reduces its share, stores
+// its partial results, takes a ticket, and the workgroup that arrives last adds the partials in a
+// fixed order and advances the scalar state (a few doubles in device memory).  The host enqueues
+// iterations in batches and looks at the `done` word between batches; an iteration launched after
+// convergence returns at once.  Same algorithms, same fp64 scalars, same stopping tests as the
+// per-segment device functions above.
+struct GridState {
+  double s[24];
+  int done;
+  int iters;
+  unsigned ticket;
+  int pad;
+};
+constexpr int kGridMaxBlocks = 1024;
+constexpr int kGridK = 3;  // partial results per workgroup
+constexpr int kGridS = 24;  // doubles of scalar state
+
+__device__ inline double WaveReduceK(double v, bool is_max) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = is_max ? fmax(v, o) : v + o;
+  }
+  return v;
+}
+
+// Op: Identity(k, s) / Acc(acc, d, s) / IsMax(k, s) / Update(s, tot, &done) / Apply(d, s)
+template <class T, class Op>
+__global__ __launch_bounds__(kBlock) void GridIterKernel(Op op, const T* __restrict__ v, int64_t n,
+                                                         int64_t stride, GridState* st,
+                                                         double* partial) {
+  __shared__ double red[kBlock / 64][kGridK];
+  __shared__ double tot[kGridK];
+  __shared__ bool last;
+  if (st->done) return;  // (written by a previous launch: visible at the kernel boundary)
+  double s[kGridS];
+#pragma unroll
+  for (int i = 0; i < kGridS; ++i) s[i] = st->s[i];
+  double acc[kGridK];
+#pragma unroll
+  for (int k = 0; k < kGridK; ++k) acc[k] = op.Identity(k, s);
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = blockIdx.x * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kBlock) op.Acc(acc, static_cast<double>(v[i * stride]), s);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kGridK; ++k) {
+    const double t = WaveReduceK(acc[k], op.IsMax(k, s));
+    if (lane == 0) red[wave][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGridK) {
+    const int k = threadIdx.x;
+    double t = red[0][k];
+    for (int w = 1; w < kBlock / 64; ++w) t = op.IsMax(k, s) ? fmax(t, red[w][k]) : t + red[w][k];
+    __hip_atomic_store(partial + blockIdx.x * kGridK + k, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = prev == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  if (threadIdx.x < kGridK) {
+    const int k = threadIdx.x;
+    const bool mx = op.IsMax(k, s);
+    double t = op.Identity(k, s);
+    for (unsigned b = 0; b < gridDim.x; ++b) {
+      const double p = __hip_atomic_load(partial + b * kGridK + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = mx ? fmax(t, p) : t + p;
+    }
+    tot[k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int done = 0;
+    double t3[kGridK];
+#pragma unroll
+    for (int k = 0; k < kGridK; ++k) t3[k] = tot[k];
+    op.Update(s, t3, &done);
+#pragma unroll
+    for (int i = 0; i < kGridS; ++i) st->s[i] = s[i];
+    st->done = done;
+    st->iters += 1;
+    __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <class T, class Op>
+__global__ __launch_bounds__(kBlock) void GridApplyKernel(Op op, T* x, const T* v, int64_t n, int64_t stride,
+                                                          const GridState* st, T* tout) {
+  double s[kGridS];
+#pragma unroll
+  for (int i = 0; i < kGridS; ++i) s[i] = st->s[i];
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    x[i * stride] = static_cast<T>(op.Apply(static_cast<double>(v[i * stride]), s));
+  if (tout != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *tout = static_cast<T>(op.OutT(s));  // epigraphs
+}
+
+// MAX prox and epigraph (MaxThreshold above): s = {t, previous count, num0, den0, phase, s_in, mode}
+// mode 0: prox, t0 = max(v) + num0 with num0 = -lam, den0 = 0; mode 1: epigraph, t0 = s_in,
+// num0 = s_in, den0 = 1, nothing to do when s_in >= max(v)
+struct GridMaxOp {
+  __device__ double Identity(int k, const double* s) const { return (s[4] == 0 && k == 0) ? -INFINITY : 0.0; }
+  __device__ bool IsMax(int k, const double* s) const { return s[4] == 0 && k == 0; }
+  __device__ void Acc(double* acc, double d, const double* s) const {
+    if (s[4] == 0) {
+      acc[0] = fmax(acc[0], d);
+    } else if (d > s[0]) {
+      acc[1] += d;
+      acc[2] += 1;
+    }
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    if (s[4] == 0) {
+      s[1] = -1;
+      s[4] = 1;
+      if (s[6] == 0) {
+        s[0] = tot[0] + s[2];
+      } else {
+        s[0] = s[5];
+        if (s[5] >= tot[0]) *done = 1;
+      }
+      return;
+    }
+    const double cnt = tot[2];
+    if (cnt == s[1] || cnt + s[3] == 0) {
+      *done = 1;
+      return;
+    }
+    s[1] = cnt;
+    s[0] = (tot[1] + s[2]) / (cnt + s[3]);
+  }
+  __device__ double Apply(double d, const double* s) const { return fmin(d, s[0]); }
+  __device__ double OutT(const double* s) const { return s[0]; }
+};
+
+// SUM_LARGEST prox (SumLargestThreshold above): s = {q, lo, hi, lam, k, phase, len}
+struct GridSumLargestProx {
+  __device__ double Identity(int k, const double* s) const { return (s[5] == 0 && k < 2) ? -INFINITY : 0.0; }
+  __device__ bool IsMax(int k, const double* s) const { return s[5] == 0 && k < 2; }
+  __device__ void Acc(double* acc, double d, const double* s) const {
+    if (s[5] == 0) {
+      acc[0] = fmax(acc[0], d);
+      acc[1] = fmax(acc[1], -d);
+    } else if (d >= s[0] + s[3]) {
+      acc[0] += 1;
+    } else if (d >= s[0]) {
+      acc[1] += 1;
+      acc[2] += d;
+    }
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    const double lam = s[3], k = s[4];
+    if (s[5] == 0) {
+      const double mx = tot[0], mn = -tot[1];
+      s[1] = mn - lam;
+      s[2] = mx;
+      s[5] = 1;
+      if (k >= s[6] || !(lam > 0)) {  // every entry gives up lam
+        s[0] = s[1];
+        *done = 1;
+        return;
+      }
+      s[0] = 0.5 * (s[1] + s[2]);
+      return;
+    }
+    double q = s[0], lo = s[1], hi = s[2];
+    const double a = tot[0], cI = tot[1], sI = tot[2];
+    const double h = a * lam + sI - cI * q - k * lam;
+    if (h == 0) {
+      *done = 1;
+      return;
+    }
+    if (h > 0) lo = q;
+    else hi = q;
+    double qn = cI > 0 ? (a * lam + sI - k * lam) / cI : 0.5 * (lo + hi);
+    s[1] = lo;
+    s[2] = hi;
+    if (cI > 0 && fabs(qn - q) <= 1e-15 * fmax(1.0, fabs(q))) {
+      s[0] = qn;
+      *done = 1;  // q is the root of its own linear piece
+      return;
+    }
+    if (!(qn > lo && qn < hi)) qn = 0.5 * (lo + hi);
+    if (qn == q || !(hi > lo)) {
+      *done = 1;
+      return;
+    }
+    s[0] = qn;
+  }
+  __device__ double Apply(double d, const double* s) const { return d - fmax(0.0, fmin(s[3], d - s[0])); }
+  __device__ double OutT(const double*) const { return 0.0; }
+};
+
+// LOG_SUM_EXP prox (LseProxLogZ above): s = {c = log Z, max, lam, log lam, phase}
+struct GridLseProx {
+  __device__ double Identity(int k, const double* s) const { return (s[4] == 0 && k == 0) ? -INFINITY : 0.0; }
+  __device__ bool IsMax(int k, const double* s) const { return s[4] == 0 && k == 0; }
+  __device__ void Acc(double* acc, double d, const double* s) const {
+    if (s[4] == 0) {
+      acc[0] = fmax(acc[0], d);
+    } else if (s[4] == 1) {
+      acc[0] += exp(d - s[1]);
+    } else {
+      const double om = LambertWExp(s[3] + d - s[0]);
+      acc[0] += om;              // lam * w_i
+      acc[1] += om / (1 + om);   // -d(om)/dc
+    }
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    if (s[4] == 0) {
+      s[1] = tot[0];
+      s[4] = 1;
+      return;
+    }
+    if (s[4] == 1) {
+      s[0] = s[1] + log(tot[0]) - s[2];  // c0 = lse(v) - lam: the residual below is >= 0 there
+      s[4] = 2;
+      return;
+    }
+    const double r = tot[0] - s[2];
+    const double step = r / tot[1];
+    if (!(step > 1e-16 * fmax(1.0, fabs(s[0])))) {
+      *done = 1;  // monotone from the left: done
+      return;
+    }
+    s[0] += step;
+  }
+  __device__ double Apply(double d, const double* s) const { return d - LambertWExp(s[3] + d - s[0]); }
+  __device__ double OutT(const double*) const { return 0.0; }
+};
+
+// Epigraph of a separable smooth function (SegSmoothEpiKernel above):
+// s = {lam, lo, hi, s_in, phase, len}; phase 0 the easy case (only when the function has one),
+// 1 the safeguarded Newton on lam, 9 "v itself (projected) is the answer"
+template <class Fn> struct GridSmoothEpi {
+  __device__ double Identity(int, const double*) const { return 0.0; }
+  __device__ bool IsMax(int, const double*) const { return false; }
+  __device__ void Acc(double* acc, double d, const double* s) const {
+    if (s[4] == 0) {
+      const double pd = Fn::proj(d);
+      acc[0] += Fn::f(pd);
+      acc[1] += (d - pd) * (d - pd);
+    } else {
+      const double xi = ProxElem<Fn>(d, s[0]);
+      const double g = Fn::g(xi);
+      acc[0] += Fn::f(xi);
+      acc[1] += g * g / (1 + s[0] * Fn::h(xi));
+    }
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    const double sin = s[3];
+    if (s[4] == 0) {
+      const double eps = fmax(1e-12, 1e-10 / s[5]);
+      if (tot[0] <= sin && (Fn::kImplicit || sqrt(tot[1]) < eps)) {
+        s[4] = 9;
+        *done = 1;
+        return;
+      }
+      s[4] = 1;
+      return;
+    }
+    double lam = s[0], lo = s[1], hi = s[2];
+    const double F = tot[0], Hs = tot[1];
+    const double phi = F - lam - sin;
+    if (fabs(phi) <= 1e-12 * fmax(1.0, fmax(fabs(F), fabs(sin)))) {
+      *done = 1;
+      return;
+    }
+    if (phi > 0) lo = lam;
+    else hi = lam;
+    double ln = lam - phi / (-Hs - 1);
+    if (!(ln > lo && ln < hi)) ln = isinf(hi) ? 2 * lam : 0.5 * (lo + hi);
+    s[1] = lo;
+    s[2] = hi;
+    if (ln == lam) {
+      *done = 1;
+      return;
+    }
+    s[0] = ln;
+  }
+  __device__ double Apply(double d, const double* s) const {
+    if (s[4] == 9) return Fn::kImplicit ? Fn::proj(d) : d;
+    return ProxElem<Fn>(d, s[0]);
+  }
+  __device__ double OutT(const double* s) const { return s[4] == 9 ? s[3] : s[3] + s[0]; }
+};
+
+// LOG_SUM_EXP epigraph (SegLseEpiKernel above): s = {c, max -> lse, lam, log lam, phase, s_in, lo, hi}
+// phase 0 max, 1 sum of exponentials, 2 the inner Newton on c = log Z at the current lam (its
+// convergence triggers the outer safeguarded Newton step on lam), 9 "v is in the epigraph"
+struct GridLseEpi {
+  __device__ double Identity(int k, const double* s) const { return (s[4] == 0 && k == 0) ? -INFINITY : 0.0; }
+  __device__ bool IsMax(int k, const double* s) const { return s[4] == 0 && k == 0; }
+  __device__ void Acc(double* acc, double d, const double* s) const {
+    if (s[4] == 0) {
+      acc[0] = fmax(acc[0], d);
+    } else if (s[4] == 1) {
+      acc[0] += exp(d - s[1]);
+    } else {
+      const double om = LambertWExp(s[3] + d - s[0]);
+      acc[0] += om;
+      acc[1] += om / (1 + om);
+      const double w = om / s[2];
+      acc[2] += w * w / (1 + om);
+    }
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    const double sin = s[5];
+    if (s[4] == 0) {
+      s[1] = tot[0];
+      s[4] = 1;
+      return;
+    }
+    if (s[4] == 1) {
+      const double lse = s[1] + log(tot[0]);
+      s[1] = lse;
+      if (lse <= sin) {
+        s[4] = 9;
+        *done = 1;
+        return;
+      }
+      s[2] = 1;            // lam
+      s[3] = 0;            // log lam
+      s[6] = 0;            // lo
+      s[7] = INFINITY;     // hi
+      s[0] = lse - s[2];   // the inner iteration starts from c = lse - lam
+      s[4] = 2;
+      return;
+    }
+    double lam = s[2];
+    const double r = tot[0] - lam;
+    const double step = r / tot[1];
+    if (step > 1e-16 * fmax(1.0, fabs(s[0]))) {  // inner Newton continues
+      s[0] += step;
+      return;
+    }
+    // c(lam) is known: the outer step
+    const double cz = s[0], t = tot[2];
+    const double phi = cz - lam - sin;
+    if (fabs(phi) <= 1e-13 * fmax(1.0, fmax(fabs(cz), fabs(sin)))) {
+      *done = 1;
+      return;
+    }
+    double lo = s[6], hi = s[7];
+    if (phi > 0) lo = lam;
+    else hi = lam;
+    double ln = lam - phi / (-t / (1 - lam * t) - 1);
+    if (!(ln > lo && ln < hi)) ln = isinf(hi) ? 2 * lam : 0.5 * (lo + hi);
+    s[6] = lo;
+    s[7] = hi;
+    if (ln == lam) {
+      *done = 1;
+      return;
+    }
+    s[2] = ln;
+    s[3] = log(ln);
+    s[0] = s[1] - ln;
+  }
+  __device__ double Apply(double d, const double* s) const {
+    if (s[4] == 9) return d;
+    return d - LambertWExp(s[3] + d - s[0]);
+  }
+  __device__ double OutT(const double* s) const { return s[4] == 9 ? s[5] : s[5] + s[2]; }
+};
+
+// SUM_LARGEST epigraph (SegSumLargestEpiKernel above): the bisection on lam with, inside it, the
+// threshold q(lam) (SumLargestThreshold) and the value of sum_largest at the prox point
+// (SumLargestEval: a bisection on the count above tau, then one pass).  Indices into s:
+enum {
+  SL_LAM = 0, SL_UPPER, SL_LOWER, SL_UPFIXED, SL_OUTER, SL_Q, SL_QLO, SL_QHI, SL_MN, SL_MX, SL_K, SL_LEN,
+  SL_SIN, SL_ELO, SL_EHI, SL_MID, SL_TOTAL, SL_PHASE, SL_SHIFTED, SL_EIT, SL_TIT, SL_FINAL, SL_EASY
+};
+// phases: 0 range + total of the values being evaluated, 1 one step of the count bisection,
+// 2 the pass above tau, 3 (no pass of its own) start of the threshold, 4 one threshold step
+struct GridSumLargestEpi {
+  __device__ double Val(double d, const double* s) const {
+    return s[SL_SHIFTED] != 0 ? d - fmax(0.0, fmin(s[SL_LAM], d - s[SL_Q])) : d;
+  }
+  __device__ double Identity(int k, const double* s) const { return (s[SL_PHASE] == 0 && k < 2) ? -INFINITY : 0.0; }
+  __device__ bool IsMax(int k, const double* s) const { return s[SL_PHASE] == 0 && k < 2; }
+  __device__ void Acc(double* acc, double d, const double* s) const {
+    const int ph = static_cast<int>(s[SL_PHASE]);
+    if (ph == 0) {
+      const double x = Val(d, s);
+      acc[0] = fmax(acc[0], x);
+      acc[1] = fmax(acc[1], -x);
+      acc[2] += x;
+    } else if (ph == 1) {
+      acc[0] += Val(d, s) > s[SL_MID] ? 1.0 : 0.0;
+    } else if (ph == 2) {
+      acc[0] += fmax(Val(d, s) - s[SL_EHI], 0.0);
+    } else {  // threshold step on the raw values
+      if (d >= s[SL_Q] + s[SL_LAM]) {
+        acc[0] += 1;
+      } else if (d >= s[SL_Q]) {
+        acc[1] += 1;
+        acc[2] += d;
+      }
+    }
+  }
+  // the count bisection's next midpoint, or on to the last pass of the evaluation
+  __device__ void NextMid(double* s) const {
+    const double mid = s[SL_ELO] + 0.5 * (s[SL_EHI] - s[SL_ELO]);
+    if (s[SL_EIT] < 200 && mid > s[SL_ELO] && mid < s[SL_EHI]) {
+      s[SL_MID] = mid;
+      s[SL_PHASE] = 1;
+    } else {
+      s[SL_PHASE] = 2;
+    }
+  }
+  __device__ void StartThreshold(double* s, int* done) const {
+    const double lam = s[SL_LAM];
+    s[SL_QLO] = s[SL_MN] - lam;
+    s[SL_QHI] = s[SL_MX];
+    if (s[SL_K] >= s[SL_LEN] || !(lam > 0)) {
+      s[SL_Q] = s[SL_QLO];
+      ThresholdDone(s, done);
+      return;
+    }
+    s[SL_Q] = 0.5 * (s[SL_QLO] + s[SL_QHI]);
+    s[SL_TIT] = 0;
+    s[SL_PHASE] = 4;
+  }
+  __device__ void ThresholdDone(double* s, int* done) const {
+    if (s[SL_FINAL] != 0) {
+      *done = 1;
+      return;
+    }
+    s[SL_SHIFTED] = 1;
+    s[SL_PHASE] = 0;  // evaluate sum_largest at the prox point
+  }
+  // f = sum_largest of the evaluated values is known
+  __device__ void ValueDone(double* s, double fval, int* done) const {
+    const double sin = s[SL_SIN];
+    if (s[SL_SHIFTED] == 0) {
+      if (fval <= sin) {
+        s[SL_EASY] = 1;
+        *done = 1;
+        return;
+      }
+      s[SL_LAM] = 1;
+      s[SL_UPPER] = 1;
+      s[SL_LOWER] = 0;
+      s[SL_UPFIXED] = 0;
+      s[SL_OUTER] = 0;
+      StartThreshold(s, done);
+      return;
+    }
+    double lam = s[SL_LAM];
+    const double g = fval - (lam + sin);
+    if (fabs(g) <= 1e-5) {
+      *done = 1;  // converged: q belongs to this lam
+      return;
+    }
+    if (g > 0 && s[SL_UPFIXED] == 0) {
+      lam *= 2;
+      s[SL_UPPER] = lam;
+    } else if (g > 0) {
+      s[SL_LOWER] = lam;
+      lam = (lam + s[SL_UPPER]) / 2;
+    } else {
+      s[SL_UPPER] = lam;
+      lam = (lam + s[SL_LOWER]) / 2;
+      s[SL_UPFIXED] = 1;
+    }
+    s[SL_LAM] = lam;
+    s[SL_OUTER] += 1;
+    if (s[SL_OUTER] >= 100) s[SL_FINAL] = 1;  // not converged: the threshold of the last lam, then stop
+    StartThreshold(s, done);
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    const int ph = static_cast<int>(s[SL_PHASE]);
+    const double k = s[SL_K];
+    if (ph == 0) {
+      const double mx = tot[0], mn = -tot[1], total = tot[2];
+      if (s[SL_SHIFTED] == 0) {  // the range of the raw values also serves every threshold
+        s[SL_MN] = mn;
+        s[SL_MX] = mx;
+      }
+      if (k >= s[SL_LEN]) {
+        ValueDone(s, total, done);
+        return;
+      }
+      s[SL_ELO] = mn - 1;
+      s[SL_EHI] = mx;
+      s[SL_EIT] = 0;
+      NextMid(s);
+    } else if (ph == 1) {
+      if (tot[0] > k) s[SL_ELO] = s[SL_MID];
+      else s[SL_EHI] = s[SL_MID];
+      s[SL_EIT] += 1;
+      NextMid(s);
+    } else if (ph == 2) {
+      ValueDone(s, k * s[SL_EHI] + tot[0], done);
+    } else {
+      const double lam = s[SL_LAM];
+      double q = s[SL_Q], lo = s[SL_QLO], hi = s[SL_QHI];
+      const double a = tot[0], cI = tot[1], sI = tot[2];
+      const double h = a * lam + sI - cI * q - k * lam;
+      if (h == 0) {
+        ThresholdDone(s, done);
+        return;
+      }
+      if (h > 0) lo = q;
+      else hi = q;
+      double qn = cI > 0 ? (a * lam + sI - k * lam) / cI : 0.5 * (lo + hi);
+      s[SL_QLO] = lo;
+      s[SL_QHI] = hi;
+      if (cI > 0 && fabs(qn - q) <= 1e-15 * fmax(1.0, fabs(q))) {
+        s[SL_Q] = qn;
+        ThresholdDone(s, done);
+        return;
+      }
+      if (!(qn > lo && qn < hi)) qn = 0.5 * (lo + hi);
+      s[SL_TIT] += 1;
+      if (qn == q || !(hi > lo) || s[SL_TIT] >= 200) {
+        ThresholdDone(s, done);
+        return;
+      }
+      s[SL_Q] = qn;
+    }
+  }
+  __device__ double Apply(double d, const double* s) const {
+    if (s[SL_EASY] != 0) return d;
+    return d - fmax(0.0, fmin(s[SL_LAM], d - s[SL_Q]));
+  }
+  __device__ double OutT(const double* s) const { return s[SL_EASY] != 0 ? s[SL_SIN] : s[SL_LAM] + s[SL_SIN]; }
+};
+static_assert(SL_EASY < kGridS, "GridState too small");
+
+// NORM_2 shrinkage of one slice (SegNorm2Kernel above): s = {scale, lam, phase}
+struct GridNorm2 {
+  __device__ double Identity(int, const double*) const { return 0.0; }
+  __device__ bool IsMax(int, const double*) const { return false; }
+  __device__ void Acc(double* acc, double d, const double*) const { acc[0] += d * d; }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    const double nv = sqrt(tot[0]), lam = s[1];
+    s[0] = (nv >= lam && nv > 0) ? 1.0 - lam / nv : 0.0;
+    *done = 1;
+  }
+  __device__ double Apply(double d, const double* s) const { return s[0] * d; }
+  __device__ double OutT(const double*) const { return 0.0; }
+};
+
+// second-order cone, one cone per slice (SegSocKernel above): s = {alpha, t, beta}
+struct GridSoc {
+  __device__ double Identity(int, const double*) const { return 0.0; }
+  __device__ bool IsMax(int, const double*) const { return false; }
+  __device__ void Acc(double* acc, double d, const double*) const { acc[0] += d * d; }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    const double vnorm = sqrt(tot[0]), beta = s[2], beta2 = beta * beta;
+    double t = s[1];
+    double alpha = (1 / (beta2 + 1)) * (beta2 + beta * t / vnorm);
+    if (isnan(alpha) || alpha > 1) {
+      alpha = 1;
+    } else if (alpha < 0) {
+      alpha = 0;
+      t = 0;
+    } else {
+      t = (1 / beta) * alpha * vnorm;
+    }
+    s[0] = alpha;
+    s[1] = t;
+    *done = 1;
+  }
+  __device__ double Apply(double d, const double* s) const { return s[0] * d; }
+  __device__ double OutT(const double* s) const { return s[1]; }
+};
+
+// scaled-zone epigraph of one slice with scalar alpha / beta (SegZoneEpiKernel above):
+// s = {lam, previous count, s_in, M, alpha, beta, phase}
+struct GridZoneEpi {
+  __device__ double Identity(int, const double*) const { return 0.0; }
+  __device__ bool IsMax(int, const double*) const { return false; }
+  __device__ void Acc(double* acc, double y, const double* s) const {
+    const double M = s[3], w = y > 0 ? s[4] : s[5];
+    if (!(fabs(y) > M && w != 0)) return;
+    const double ex = fabs(y) - M;
+    if (s[6] == 0) {
+      acc[0] += w * ex;
+    } else if (ex / w > s[0]) {
+      acc[0] += w * ex;
+      acc[1] += w * w;
+      acc[2] += 1;
+    }
+  }
+  __device__ void Update(double* s, const double* tot, int* done) const {
+    if (s[6] == 0) {
+      s[0] = 0;
+      s[1] = -1;
+      s[6] = 1;
+      if (tot[0] <= s[2]) *done = 1;
+      return;
+    }
+    if (tot[2] == s[1]) {
+      *done = 1;
+      return;
+    }
+    s[1] = tot[2];
+    s[0] = (tot[0] - s[2]) / (tot[1] + 1);
+  }
+  __device__ double Apply(double y, const double* s) const {  // ApplyScaledZone (scaled_zone.cc:78-104)
+    const double lam = s[0], M = s[3], a = s[4], b = s[5];
+    if (fabs(y) <= M) return y;
+    if (y > M + lam * a) return y - lam * a;
+    if (y < -M - lam * b) return y + lam * b;
+    return y > 0 ? M : -M;
+  }
+  __device__ double OutT(const double* s) const { return s[2] + s[0]; }
+};
+
+// slices at least this long, and few of them, take the grid-wide route
+constexpr int64_t kGridMinLen = int64_t(1) << 17;
+inline bool UseGridRoute(const Segs& S) {
+  const char* e = std::getenv("EPSILON_HIP_SEG_GRID");  // "0": one workgroup per slice whatever its length
+  if (e && e[0] == '0') return false;                  // (read per call: the tests compare the two routes)
+  return S.count >= 1 && S.count <= 8 && S.len >= kGridMinLen;
+}
+
+template <class T, class Op>
+void RunGridSlice(const Op& op, T* x, const T* v, int64_t n, int64_t stride, const double* init, int ninit,
+                  int max_iters, T* tout = nullptr) {
+  Runtime& rt = Runtime::Get();
+  hipStream_t st = rt.stream();
+  auto sbuf = rt.Alloc(sizeof(GridState));
+  auto pbuf = rt.Alloc(sizeof(double) * kGridMaxBlocks * kGridK);
+  GridState h{};
+  for (int i = 0; i < ninit && i < kGridS; ++i) h.s[i] = init[i];
+  EPS_HIP(hipMemcpyAsync(sbuf->p, &h, sizeof(h), hipMemcpyHostToDevice, st));
+  EPS_HIP(hipStreamSynchronize(st));  // (h is a stack object)
+  GridState* gs = static_cast<GridState*>(sbuf->p);
+  double* partial = static_cast<double*>(pbuf->p);
+  int64_t grid = (n + 8 * kBlock - 1) / (8 * kBlock);
+  grid = std::min<int64_t>(std::max<int64_t>(grid, 1), kGridMaxBlocks);
+  int launched = 0, batch = 8;
+  while (launched < max_iters) {
+    const int nb = std::min(batch, max_iters - launched);
+    for (int i = 0; i < nb; ++i)
+      hipLaunchKernelGGL((GridIterKernel<T, Op>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, st, op, v, n,
+                         stride, gs, partial);
+    launched += nb;
+    int done = 0;
+    EPS_HIP(hipMemcpyAsync(&done, &gs->done, sizeof(int), hipMemcpyDeviceToHost, st));
+    EPS_HIP(hipStreamSynchronize(st));
+    if (done) break;
+    if (batch < 64) batch *= 2;  // long iterations (nested loops): fewer host round trips
+  }
+  hipLaunchKernelGGL((GridApplyKernel<T, Op>), dim3(static_cast<unsigned>(grid)), dim3(kBlock), 0, st, op, x, v, n,
+                     stride, gs, tout);
+  EPS_HIP(hipGetLastError());
+}
+
+// the scalar inputs of the (few) slices of an epigraph, on the host
+inline std::vector<double> HostScalars(const DVec& s) { return s.ToHost(); }
+
 // ---- launch helpers ---------------------------------------------------------------------------------------
 
 int GroupFor(const Segs& S) {
@@ -823,6 +1493,14 @@ void SegNorm2Shrink(const DVec& x, const DVec& v, double lam, const Segs& S) {
   CheckSegs(S, v.n);
   if (v.n == 0) return;
   ProfScope prof("seg_norm2", S.count, S.len);
+  if (UseGridRoute(S)) {
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[3] = {0, lam, 0};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridNorm2{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 3, 1));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegNorm2Kernel, x.as<T>(), v.as<T>(), lam, S));
 }
 
@@ -831,6 +1509,14 @@ void SegMaxProx(const DVec& x, const DVec& v, double lam, const Segs& S) {
   CheckSegs(S, v.n);
   if (v.n == 0) return;
   ProfScope prof("seg_max", S.count, S.len);
+  if (UseGridRoute(S)) {  // long slices: every reduction on the whole grid
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[7] = {0, -1, -lam, 0, 0, 0, 0};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridMaxOp{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 7, 256 + 1));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegMaxProxKernel, x.as<T>(), v.as<T>(), lam, S));
 }
 
@@ -840,6 +1526,15 @@ void SegMaxEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s, 
   CheckSegs(S, v.n);
   if (S.count == 0) return;
   ProfScope prof("seg_max_epi", S.count, S.len);
+  if (UseGridRoute(S)) {
+    const std::vector<double> sh = HostScalars(s);
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[7] = {0, -1, sh[g], 1, 0, sh[g], 1};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridMaxOp{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 7, 256 + 1, t.as<T>() + g));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegMaxEpiKernel, x.as<T>(), t.as<T>(), v.as<T>(),
                                       s.as<T>(), S));
 }
@@ -849,6 +1544,14 @@ void SegSumLargestProx(const DVec& x, const DVec& v, double lam, int k, const Se
   CheckSegs(S, v.n);
   if (v.n == 0) return;
   ProfScope prof("seg_sum_largest", S.count, S.len);
+  if (UseGridRoute(S)) {
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[8] = {0, 0, 0, lam, static_cast<double>(k), 0, static_cast<double>(S.len), 0};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridSumLargestProx{}, x.as<T>() + g * S.seg_stride,
+                                           v.as<T>() + g * S.seg_stride, S.len, S.elem_stride, init, 8, 200 + 1));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegSumLargestKernel, x.as<T>(), v.as<T>(), lam,
                                       static_cast<double>(k), S));
 }
@@ -860,6 +1563,20 @@ void SegSumLargestEpigraph(const DVec& x, const DVec& t, const DVec& v, const DV
   CheckSegs(S, v.n);
   if (S.count == 0) return;
   ProfScope prof("seg_sum_largest_epi", S.count, S.len);
+  if (UseGridRoute(S)) {
+    const std::vector<double> sh = HostScalars(s);
+    for (int64_t g = 0; g < S.count; ++g) {
+      double init[kGridS] = {};
+      init[SL_K] = static_cast<double>(k);
+      init[SL_LEN] = static_cast<double>(S.len);
+      init[SL_SIN] = sh[g];
+      // outer bisection x (threshold steps + count bisection + 3 passes): a generous bound
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridSumLargestEpi{}, x.as<T>() + g * S.seg_stride,
+                                           v.as<T>() + g * S.seg_stride, S.len, S.elem_stride, init, kGridS,
+                                           101 * 410, t.as<T>() + g));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegSumLargestEpiKernel, x.as<T>(), t.as<T>(), v.as<T>(),
                                       s.as<T>(), static_cast<double>(k), S));
 }
@@ -874,6 +1591,15 @@ void SegZoneEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s,
   CheckSegs(S, v.n);
   if (S.count == 0) return;
   ProfScope prof("seg_zone_epi", S.count, S.len);
+  if (UseGridRoute(S) && alpha_vec == nullptr && beta_vec == nullptr) {
+    const std::vector<double> sh = HostScalars(s);
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[7] = {0, -1, sh[g], M, alpha, beta, 0};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridZoneEpi{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 7, 256 + 1, t.as<T>() + g));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegZoneEpiKernel, x.as<T>(), t.as<T>(), v.as<T>(),
                                       s.as<T>(), alpha, beta,
                                       alpha_vec ? alpha_vec->as<T>() : nullptr,
@@ -887,6 +1613,15 @@ void SegSocProject(const DVec& x, const DVec& t, const DVec& v, const DVec& tin,
   CheckSegs(S, v.n);
   if (S.count == 0) return;
   ProfScope prof("seg_soc", S.count, S.len);
+  if (UseGridRoute(S)) {
+    const std::vector<double> th = HostScalars(tin);
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[3] = {0, th[g], beta};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridSoc{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 3, 1, t.as<T>() + g));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegSocKernel, x.as<T>(), t.as<T>(), v.as<T>(),
                                       tin.as<T>(), beta, S));
 }
@@ -896,6 +1631,14 @@ void SegLogSumExpProx(const DVec& x, const DVec& v, double lam, const Segs& S) {
   CheckSegs(S, v.n);
   if (v.n == 0) return;
   ProfScope prof("seg_lse", S.count, S.len);
+  if (UseGridRoute(S) && lam > 0) {
+    for (int64_t g = 0; g < S.count; ++g) {
+      const double init[8] = {0, 0, lam, std::log(lam), 0, 0, 0, 0};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridLseProx{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 8, 100 + 2));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegLseProxKernel, x.as<T>(), v.as<T>(), lam, S));
 }
 
@@ -906,6 +1649,15 @@ void SegLogSumExpEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVe
   CheckSegs(S, v.n);
   if (S.count == 0) return;
   ProfScope prof("seg_lse_epi", S.count, S.len);
+  if (UseGridRoute(S)) {
+    const std::vector<double> sh = HostScalars(s);
+    for (int64_t g = 0; g < S.count; ++g) {
+      double init[8] = {0, 0, 0, 0, 0, sh[g], 0, 0};
+      EPS_DISPATCH_T(v.dt, RunGridSlice<T>(GridLseEpi{}, x.as<T>() + g * S.seg_stride, v.as<T>() + g * S.seg_stride,
+                                           S.len, S.elem_stride, init, 8, 200 * 101 + 2, t.as<T>() + g));
+    }
+    return;
+  }
   EPS_DISPATCH_T(v.dt, EPS_LAUNCH_SEG(S, SegLseEpiKernel, x.as<T>(), t.as<T>(), v.as<T>(),
                                       s.as<T>(), S));
 }
@@ -950,6 +1702,20 @@ void SegSmoothEpigraph(SmoothFn fn, const DVec& x, const DVec& t, const DVec& v,
   CheckSegs(S, v.n);
   if (S.count == 0) return;
   ProfScope prof("seg_smooth_epi", S.count, S.len);
+  if (UseGridRoute(S)) {
+    const std::vector<double> sh = HostScalars(s);
+    for (int64_t sg = 0; sg < S.count; ++sg) {
+      EPS_DISPATCH_T(v.dt, EPS_SMOOTH_SWITCH(fn, {
+                       const double lam_min = Fn::kNoEasy ? 1e-10 : 0.0;
+                       const double init[6] = {1, lam_min, INFINITY, sh[sg], Fn::kNoEasy ? 1.0 : 0.0,
+                                               static_cast<double>(S.len)};
+                       RunGridSlice<T>(GridSmoothEpi<Fn>{}, x.as<T>() + sg * S.seg_stride,
+                                       v.as<T>() + sg * S.seg_stride, S.len, S.elem_stride, init, 6, 200 + 1,
+                                       t.as<T>() + sg);
+                     }));
+    }
+    return;
+  }
   const int g = GroupFor(S);
   const int64_t per_block = kBlock / g;
   const dim3 grid(static_cast<unsigned>((S.count + per_block - 1) / per_block));

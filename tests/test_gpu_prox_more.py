@@ -488,3 +488,81 @@ def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
     assert any(t.startswith("partial_svd") for t in names), names
     full = ("block_jacobi_svd:%dx%d" % (m, n)) in names or ("jacobi_svd:%dx%d" % (m, n)) in names
     assert full == (case in ("full_rank", "edge_at_threshold")), (case, names)
+
+
+@pytest.mark.parametrize("name", ["max", "sum_largest_9", "log_sum_exp"])
+@pytest.mark.parametrize("shape", [(200001, 1), (3, 150000)])
+def test_vector_prox_long_slices(solve_mod, dtype, name, shape):
+    """Slices of 131072 entries and more are solved with every reduction on the whole grid (one
+    launch per iteration of the scalar equation, the last-arriving workgroup advances the state)
+    instead of by one workgroup: one long vector, and three long rows of a matrix through the axis
+    form (strided slices).  Same oracle, same tolerances as the short slices."""
+    typ, kw = VECTOR_PROX[name]
+    rng = np.random.RandomState(5)
+    m, n = shape
+    if n == 1:
+        x = ir.variable(m, 1, "var:x")
+        v = rng.randn(m)
+        e = ir.prox(typ, x, **kw)
+    else:
+        x = ir.variable(m, n, "var:x")
+        v = rng.randn(m * n)
+        e = ir.prox(typ, x, has_axis=True, axis=1, **kw)   # one slice per row (stride m)
+    run(solve_mod, e, 0.7, {"var:x": v}, tol_for(dtype))
+
+
+LONG_EPIGRAPHS = ["max", "sum_largest_4", "log_sum_exp", "sum_exp", "sum_logistic", "sum_neg_entr",
+                  "sum_inv_pos", "sum_neg_log"]
+
+
+@pytest.mark.parametrize("name", LONG_EPIGRAPHS)
+def test_vector_epigraph_long_slice_routes_agree(solve_mod, dtype, name):
+    """Epigraph projections of one long slice (140 000 entries): the grid-wide route (every
+    reduction of the scalar iteration one launch of the whole chip) against the one-workgroup
+    route of the same library (EPSILON_HIP_SEG_GRID=0), which the short-slice tests hold to the
+    oracle.  Same algorithm, same fp64 scalars: they differ by the summation order only.  An
+    infeasible point, and a feasible one (the easy case)."""
+    import os
+    typ, kw = EPIGRAPHS[name]
+    n = 140000
+    x, t = ir.variable(n, 1, "var:x"), ir.variable(1, 1, "var:t")
+    e = ir.prox(typ, x, t, epigraph=True, **kw)
+    fb = e.proto.SerializeToString()
+    rng = np.random.RandomState(21)
+    v = np.abs(rng.randn(n)) * 0.5 + 0.2
+    for s_in in (-3.0, 1e9):
+        vb = {"var:x": v.tobytes(), "var:t": np.array([s_in]).tobytes()}
+        got = {k: np.frombuffer(b) for k, b in solve_mod.eval_prox(fb, 1.0, e.data, vb).items()}
+        os.environ["EPSILON_HIP_SEG_GRID"] = "0"
+        try:
+            ref = {k: np.frombuffer(b) for k, b in solve_mod.eval_prox(fb, 1.0, e.data, vb).items()}
+        finally:
+            os.environ.pop("EPSILON_HIP_SEG_GRID", None)
+        tol = dict(rtol=1e-9, atol=1e-9) if dtype == "f64" else dict(rtol=2e-5, atol=2e-5)
+        if name == "sum_largest_4":  # both stop their bisection at |g| <= 1e-5: same bracket sequence
+            tol = dict(rtol=1e-6, atol=1e-6) if dtype == "f64" else dict(rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["var:x"], ref["var:x"], err_msg=name, **tol)
+        np.testing.assert_allclose(got["var:t"], ref["var:t"], err_msg=name, **tol)
+
+
+def test_long_slices_norm2_soc_zone_epigraph(solve_mod, dtype):
+    """The single-reduction operators and the Michelot iteration on long slices (grid-wide route):
+    NORM_2 per row of a 2 x 140000 matrix, one second-order cone of 150000 entries, and the
+    scaled-zone epigraph (hinge, deadzone) per column of a 140000 x 2 matrix - against the
+    oracle."""
+    rng = np.random.RandomState(17)
+    m, n = 2, 140000
+    X = ir.variable(m, n, "var:X")
+    run(solve_mod, ir.prox(ProxFunction.NORM_2, X, has_axis=True, axis=1), 40.0,
+        {"var:X": rng.randn(m * n)}, tol_for(dtype))
+    N1 = 150000
+    x, t = ir.variable(N1, 1, "var:x"), ir.variable(1, 1, "var:t")
+    e = ir.prox(ProxFunction.SECOND_ORDER_CONE, t, x, arg_size=[(1, 1), (1, N1)])
+    for s in (500.0, 100.0, -100.0, -500.0):
+        run(solve_mod, e, 1.0, {"var:x": rng.randn(N1), "var:t": [s]}, tol_for(dtype, f64=1e-11, f32=2e-5))
+    Y = ir.variable(n, m, "var:Y")
+    tv = ir.variable(1, m, "var:t")
+    for typ, kw in ((ProxFunction.SUM_HINGE, {}),
+                    (ProxFunction.SUM_DEADZONE, dict(scaled_zone_params=wire.ProxScaledZoneParams(m=0.3)))):
+        ez = ir.prox(typ, Y, tv, epigraph=True, has_axis=True, axis=0, **kw)
+        run(solve_mod, ez, 1.0, {"var:Y": rng.randn(n * m), "var:t": [100.0, 1e7]}, tol_for(dtype))
