@@ -523,7 +523,7 @@ std::shared_ptr<const DenseMatrixImpl> ToDense(const LinearMapImpl& A, DType dt)
     case SPARSE_MATRIX: {
       const auto& S = static_cast<const SparseMatrixImpl&>(A);
       DVec W = DVec::Zeros(m * n, S.dtype());
-      k::ScatterAddCsc(S.csr_of_transpose(), 1.0, W);
+      k::ScatterAddCsc(S.csr_of_transpose(), S.scale(), W);
       return std::make_shared<DenseMatrixImpl>(W, m, n, false, 1.0);
     }
     default:
@@ -587,6 +587,31 @@ ImplPtr MultiplyScalarKron(const ScalarMatrixImpl& S, const KroneckerProductImpl
 ImplPtr MultiplyDenseSparse(const DenseMatrixImpl& A, const SparseMatrixImpl& S);
 
 ImplPtr MultiplyViaSparse(const LinearMapImpl& L, const LinearMapImpl& R) {
+  // a scalar / diagonal factor only scales the rows or columns of the sparse one: one pass over
+  // its values instead of a general sparse product with a diagonal matrix built for the purpose
+  // (60-80 ms each on a 7.5e6-entry data matrix, five of them in one lasso setup)
+  auto diag_of = [](const LinearMapImpl& D, std::vector<double>* d) {
+    if (D.type() == SCALAR_MATRIX) {
+      d->assign(1, static_cast<const ScalarMatrixImpl&>(D).alpha());
+      return true;
+    }
+    if (D.type() == DIAGONAL_MATRIX) {
+      *d = static_cast<const DiagonalMatrixImpl&>(D).diagonal();
+      return true;
+    }
+    return false;
+  };
+  std::vector<double> d;
+  if (R.type() == SPARSE_MATRIX && diag_of(L, &d)) {
+    const auto& SR = static_cast<const SparseMatrixImpl&>(R);
+    if (d.size() == 1) return SR.Scaled(d[0]);  // a lazy factor: shares every array
+    return std::make_shared<SparseMatrixImpl>(CscScaleRows(SR.csc(), d), SR.dtype());
+  }
+  if (L.type() == SPARSE_MATRIX && diag_of(R, &d)) {
+    const auto& SL = static_cast<const SparseMatrixImpl&>(L);
+    if (d.size() == 1) return SL.Scaled(d[0]);
+    return std::make_shared<SparseMatrixImpl>(CscScaleCols(SL.csc(), d), SL.dtype());
+  }
   if (L.type() == SPARSE_MATRIX && R.type() == SPARSE_MATRIX) {
     // A sparse-sparse product that is really a dense contraction (the Gram matrix A A^T of a
     // 10 % dense 1500 x 50000 data matrix is 10^9 multiply-adds through Gustavson's row merges,
@@ -594,8 +619,8 @@ ImplPtr MultiplyViaSparse(const LinearMapImpl& L, const LinearMapImpl& R) {
     // hand the result back in the Sparse type the reference's table prescribes.
     const auto& SL = static_cast<const SparseMatrixImpl&>(L);
     const auto& SR = static_cast<const SparseMatrixImpl&>(R);
-    const HostCsc& A = SL.csc();
-    const HostCsc& B = SR.csc();
+    const HostCsc& A = SL.csc_unscaled();  // (structure only: no scaled copy for an estimate)
+    const HostCsc& B = SR.csc_unscaled();
     std::vector<int64_t> brow(static_cast<size_t>(B.m), 0);
     for (int32_t r : B.rowidx) ++brow[static_cast<size_t>(r)];
     double work = 0;
@@ -615,7 +640,7 @@ ImplPtr MultiplyDenseSparse(const DenseMatrixImpl& A, const SparseMatrixImpl& S)
   // reference :39-45 (Dense result).  Output column j is a sparse combination of A's columns.
   DVec Am = A.Materialize(false);
   DVec C = DVec::Empty(A.m() * S.n(), A.dtype());
-  k::DenseSpmmCsc(S.csr_of_transpose(), 1.0, Am, A.m(), A.m(), C);
+  k::DenseSpmmCsc(S.csr_of_transpose(), S.scale(), Am, A.m(), A.m(), C);
   return std::make_shared<DenseMatrixImpl>(C, A.m(), S.n(), false, 1.0);
 }
 
@@ -623,7 +648,7 @@ ImplPtr MultiplySparseDense(const SparseMatrixImpl& S, const DenseMatrixImpl& B)
   // reference :71-77 (Dense result)
   DVec Bm = B.Materialize(false);
   DVec C = DVec::Empty(S.m() * B.n(), B.dtype());
-  k::SpmmCsrDense(S.csr(), 1.0, Bm, B.m(), B.n(), C);
+  k::SpmmCsrDense(S.csr(), S.scale(), Bm, B.m(), B.n(), C);
   return std::make_shared<DenseMatrixImpl>(C, S.m(), B.n(), false, 1.0);
 }
 
@@ -747,7 +772,7 @@ ImplPtr Add(const LinearMapImpl& L, const LinearMapImpl& R) {
       const auto& D = static_cast<const DenseMatrixImpl&>(a == DENSE_MATRIX ? L : R);
       const auto& S = static_cast<const SparseMatrixImpl&>(a == DENSE_MATRIX ? R : L);
       DVec C = D.Materialize(true);
-      k::ScatterAddCsc(S.csr_of_transpose(), 1.0, C);
+      k::ScatterAddCsc(S.csr_of_transpose(), S.scale(), C);
       return std::make_shared<DenseMatrixImpl>(C, D.m(), D.n(), false, 1.0);
     }
     return AddViaSparse(L, R);  // reference :65-98

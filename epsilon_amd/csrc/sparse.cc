@@ -1,5 +1,9 @@
 #include "sparse.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -11,7 +15,32 @@ namespace eps {
 
 // ---- host CSC structure algebra (setup time only) ---------------------------------------------
 
+namespace {
+// host-side timing of the setup algebra on stderr (EPSILON_HIP_INIT_TRACE=2)
+struct HostTrace {
+  const char* name;
+  int64_t a, b;
+  std::chrono::steady_clock::time_point t0;
+  bool on;
+  HostTrace(const char* n, int64_t a_ = 0, int64_t b_ = 0) : name(n), a(a_), b(b_) {
+    static const bool enabled = [] {
+      const char* e = std::getenv("EPSILON_HIP_INIT_TRACE");
+      return e && e[0] == '2';
+    }();
+    on = enabled;
+    if (on) t0 = std::chrono::steady_clock::now();
+  }
+  ~HostTrace() {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms >= 1.0) std::fprintf(stderr, "[host] %-22s %8.2f ms  (%lld, %lld)\n", name, ms,
+                                static_cast<long long>(a), static_cast<long long>(b));
+  }
+};
+}  // namespace
+
 HostCsc CscTranspose(const HostCsc& A) {
+  HostTrace trace_("CscTranspose", static_cast<int64_t>(A.rowidx.size()), static_cast<int64_t>(A.n));
   HostCsc T;
   T.m = A.n;
   T.n = A.m;
@@ -31,7 +60,33 @@ HostCsc CscTranspose(const HostCsc& A) {
   return T;
 }
 
+HostCsc CscScaleRows(const HostCsc& A, const std::vector<double>& d) {
+  HostTrace trace_("CscScaleRows", static_cast<int64_t>(A.rowidx.size()), static_cast<int64_t>(d.size()));
+  HostCsc S = A;
+  if (d.size() == 1) {
+    for (double& v : S.val) v *= d[0];
+  } else {
+    EPS_CHECK(static_cast<int64_t>(d.size()) == A.m);
+    for (size_t q = 0; q < S.val.size(); ++q) S.val[q] *= d[static_cast<size_t>(S.rowidx[q])];
+  }
+  return S;
+}
+
+HostCsc CscScaleCols(const HostCsc& A, const std::vector<double>& d) {
+  HostTrace trace_("CscScaleCols", static_cast<int64_t>(A.rowidx.size()), static_cast<int64_t>(d.size()));
+  HostCsc S = A;
+  if (d.size() == 1) {
+    for (double& v : S.val) v *= d[0];
+  } else {
+    EPS_CHECK(static_cast<int64_t>(d.size()) == A.n);
+    for (int64_t j = 0; j < A.n; ++j)
+      for (int32_t q = S.colptr[j]; q < S.colptr[j + 1]; ++q) S.val[q] *= d[static_cast<size_t>(j)];
+  }
+  return S;
+}
+
 HostCsc CscAdd(const HostCsc& A, const HostCsc& B) {
+  HostTrace trace_("CscAdd", static_cast<int64_t>(A.rowidx.size()), static_cast<int64_t>(B.rowidx.size()));
   EPS_CHECK(A.m == B.m && A.n == B.n);
   HostCsc C;
   C.m = A.m;
@@ -60,6 +115,7 @@ HostCsc CscAdd(const HostCsc& A, const HostCsc& B) {
 }
 
 HostCsc CscMultiply(const HostCsc& A, const HostCsc& B) {
+  HostTrace trace_("CscMultiply", static_cast<int64_t>(A.rowidx.size()), static_cast<int64_t>(B.rowidx.size()));
   // Gustavson, one column of C at a time: C(:,j) = sum_k A(:,k) B(k,j)
   EPS_CHECK(A.n == B.m);
   HostCsc C;
@@ -131,6 +187,7 @@ HostCsc CscDiagonal(const std::vector<double>& d) {
 }
 
 HostCsc CscFromDense(const std::vector<double>& D, int64_t m, int64_t n) {
+  HostTrace trace_("CscFromDense", static_cast<int64_t>(m), static_cast<int64_t>(n));
   HostCsc C;
   C.m = m;
   C.n = n;
@@ -171,6 +228,7 @@ bool CscIsScalar(const HostCsc& A, double* alpha) {
 }
 
 HostCsc CscFromBlob(const pb::Constant& c, const void* bytes, size_t len) {
+  HostTrace trace_("CscFromBlob", static_cast<int64_t>(static_cast<int64_t>(len)), static_cast<int64_t>(0));
   EPS_CHECK_MSG(c.constant_type == pb::Constant::SPARSE_MATRIX, "constant is not a sparse matrix");
   const int64_t m = c.m, n = c.n, nnz = c.nnz;
   EPS_CHECK_MSG(len == static_cast<size_t>(nnz) * sizeof(double) +
@@ -226,14 +284,34 @@ HostCsc CscFromBlob(const pb::Constant& c, const void* bytes, size_t len) {
 
 // ---- SparseMatrixImpl -----------------------------------------------------------------------------
 
-SparseMatrixImpl::SparseMatrixImpl(HostCsc A, DType dt)
-    : LinearMapImpl(SPARSE_MATRIX), A_(std::move(A)), dt_(dt) {
-  EPS_CHECK(static_cast<int64_t>(A_.colptr.size()) == A_.n + 1);
+SparseMatrixImpl::SparseMatrixImpl(HostCsc A, DType dt) : LinearMapImpl(SPARSE_MATRIX), dt_(dt) {
+  EPS_CHECK(static_cast<int64_t>(A.colptr.size()) == A.n + 1);
+  auto core = std::make_shared<SparseCore>();
+  core->A = std::make_shared<const HostCsc>(std::move(A));
+  core_ = core;
+}
+
+SparseMatrixImpl::SparseMatrixImpl(std::shared_ptr<const SparseCore> core, bool transposed, double scale,
+                                   DType dt)
+    : LinearMapImpl(SPARSE_MATRIX), core_(std::move(core)), transposed_(transposed), scale_(scale), dt_(dt) {
+  EPS_CHECK(core_ != nullptr && core_->A != nullptr);
+}
+
+const HostCsc& SparseCore::Transposed() const {
+  if (!At) At = std::make_shared<const HostCsc>(CscTranspose(*A));
+  return *At;
+}
+
+const HostCsc& SparseMatrixImpl::csc() const {
+  const HostCsc& base = transposed_ ? core_->Transposed() : *core_->A;
+  if (scale_ == 1.0) return base;
+  if (!scaled_) scaled_ = std::make_shared<const HostCsc>(CscScaleRows(base, std::vector<double>(1, scale_)));
+  return *scaled_;
 }
 
 std::string SparseMatrixImpl::DebugString() const {
   std::ostringstream os;
-  os << "sparse matrix " << A_.m << " x " << A_.n << " nnz=" << A_.nnz();
+  os << "sparse matrix " << m() << " x " << n() << " nnz=" << core_->A->nnz();
   return os.str();
 }
 
@@ -251,6 +329,7 @@ std::shared_ptr<Buffer> UploadI32(const std::vector<int32_t>& v) {
 
 // the CSC arrays of a matrix are the CSR arrays of its transpose
 std::shared_ptr<DeviceCsr> UploadAsCsrOfTranspose(const HostCsc& A, DType dt) {
+  HostTrace trace_("UploadCsr", A.nnz(), A.n);
   auto d = std::make_shared<DeviceCsr>();
   d->rows = A.n;
   d->cols = A.m;
@@ -260,31 +339,39 @@ std::shared_ptr<DeviceCsr> UploadAsCsrOfTranspose(const HostCsc& A, DType dt) {
   d->val = DVec::FromHost(A.val.data(), A.nnz(), dt);
   return d;
 }
+
+const DeviceCsr& CoreCsrOfA(const SparseCore& c, DType dt) {
+  if (!c.csr_a) c.csr_a = UploadAsCsrOfTranspose(c.Transposed(), dt);
+  return *c.csr_a;
+}
+const DeviceCsr& CoreCsrOfAt(const SparseCore& c, DType dt) {
+  if (!c.csr_at) c.csr_at = UploadAsCsrOfTranspose(*c.A, dt);
+  return *c.csr_at;
+}
 }  // namespace
 
-const DeviceCsr& SparseMatrixImpl::csr_of_transpose() const {
-  if (!csr_t_) csr_t_ = UploadAsCsrOfTranspose(A_, dt_);
-  return *csr_t_;
+const DeviceCsr& SparseMatrixImpl::csr() const {
+  return transposed_ ? CoreCsrOfAt(*core_, dt_) : CoreCsrOfA(*core_, dt_);
 }
 
-const DeviceCsr& SparseMatrixImpl::csr() const {
-  if (!csr_) csr_ = UploadAsCsrOfTranspose(CscTranspose(A_), dt_);
-  return *csr_;
+const DeviceCsr& SparseMatrixImpl::csr_of_transpose() const {
+  return transposed_ ? CoreCsrOfA(*core_, dt_) : CoreCsrOfAt(*core_, dt_);
 }
 
 std::shared_ptr<const LinearMapImpl> SparseMatrixImpl::Transpose() const {
-  auto T = std::make_shared<SparseMatrixImpl>(CscTranspose(A_), dt_);
-  T->csr_ = csr_t_;  // what is already resident serves the transpose too
-  T->csr_t_ = csr_;
-  return T;
+  return std::make_shared<SparseMatrixImpl>(core_, !transposed_, scale_, dt_);
+}
+
+std::shared_ptr<const LinearMapImpl> SparseMatrixImpl::Scaled(double alpha) const {
+  return std::make_shared<SparseMatrixImpl>(core_, transposed_, scale_ * alpha, dt_);
 }
 
 std::shared_ptr<const LinearMapImpl> SparseMatrixImpl::Inverse() const {
   // reference sparse_matrix_impl.cc:60-78: a multiple of the identity inverts as a scalar map,
   // anything else is densified and inverted as a dense matrix.
-  EPS_CHECK_MSG(A_.m == A_.n, "inverting non-square sparse matrix");
+  EPS_CHECK_MSG(m() == n(), "inverting non-square sparse matrix");
   double alpha;
-  if (CscIsScalar(A_, &alpha)) return ScalarMatrixImpl(A_.n, alpha).Inverse();
+  if (CscIsScalar(csc(), &alpha)) return ScalarMatrixImpl(n(), alpha).Inverse();
   return ToDense(*this, dt_)->Inverse();
 }
 
@@ -296,15 +383,16 @@ bool SparseMatrixImpl::Equals(const LinearMapImpl&) const {
 }
 
 void SparseMatrixImpl::Apply(double alpha, const DVec& x, double beta, const DVec& y) const {
-  EPS_CHECK_MSG(x.n == A_.n && y.n == A_.m,
-                "sparse map " << A_.m << " x " << A_.n << " applied to " << x.n << " -> " << y.n);
-  k::SpmvCsr(csr(), alpha, x, beta, y);
+  EPS_CHECK_MSG(x.n == n() && y.n == m(),
+                "sparse map " << m() << " x " << n() << " applied to " << x.n << " -> " << y.n);
+  k::SpmvCsr(csr(), alpha * scale_, x, beta, y);
 }
 
 std::vector<double> SparseMatrixImpl::AsDenseHost() const {
-  std::vector<double> D(static_cast<size_t>(A_.m * A_.n), 0.0);
-  for (int64_t j = 0; j < A_.n; ++j)
-    for (int32_t p = A_.colptr[j]; p < A_.colptr[j + 1]; ++p) D[A_.rowidx[p] + j * A_.m] = A_.val[p];
+  const HostCsc& A = csc();
+  std::vector<double> D(static_cast<size_t>(A.m * A.n), 0.0);
+  for (int64_t j = 0; j < A.n; ++j)
+    for (int32_t p = A.colptr[j]; p < A.colptr[j + 1]; ++p) D[A.rowidx[p] + j * A.m] = A.val[p];
   return D;
 }
 

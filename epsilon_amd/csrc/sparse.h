@@ -28,6 +28,9 @@ struct HostCsc {
 };
 
 HostCsc CscTranspose(const HostCsc& A);
+// diag(d) * A (rows scaled) / A * diag(d) (columns scaled); d of size 1 = a scalar
+HostCsc CscScaleRows(const HostCsc& A, const std::vector<double>& d);
+HostCsc CscScaleCols(const HostCsc& A, const std::vector<double>& d);
 HostCsc CscAdd(const HostCsc& A, const HostCsc& B);
 HostCsc CscMultiply(const HostCsc& A, const HostCsc& B);
 HostCsc CscKron(const HostCsc& A, const HostCsc& B);
@@ -49,11 +52,27 @@ struct DeviceCsr {
   const int32_t* colidx() const { return static_cast<const int32_t*>(idx->p); }
 };
 
+// What every handle on one sparse matrix shares: the host CSC arrays as they arrived, their
+// transpose (built on first use, once), and the device CSR forms of both.
+struct SparseCore {
+  std::shared_ptr<const HostCsc> A;            // as constructed
+  mutable std::shared_ptr<const HostCsc> At;   // CscTranspose(*A), lazily
+  mutable std::shared_ptr<DeviceCsr> csr_a;    // CSR of A   (= the arrays of At)
+  mutable std::shared_ptr<DeviceCsr> csr_at;   // CSR of A^T (= the arrays of A)
+  const HostCsc& Transposed() const;
+};
+
+// A sparse map = (core, transposed?, scalar factor): transposing and multiplying by a scalar are
+// O(1) and share everything - as the dense maps do (the reference's Eigen expressions copy the
+// 7.5e6-entry data matrix of its lasso_sparse benchmark for each of them; the first version here
+// did too: five 60-80 ms sparse products with a diagonal and four 40 ms transposes in one setup).
+// The device CSR arrays carry the UNSCALED values: callers fold scale() into their alpha.
 class SparseMatrixImpl final : public LinearMapImpl {  // linear/sparse_matrix_impl.h:12-38
  public:
   SparseMatrixImpl(HostCsc A, DType dt);
-  int64_t m() const override { return A_.m; }
-  int64_t n() const override { return A_.n; }
+  SparseMatrixImpl(std::shared_ptr<const SparseCore> core, bool transposed, double scale, DType dt);
+  int64_t m() const override { return transposed_ ? core_->A->n : core_->A->m; }
+  int64_t n() const override { return transposed_ ? core_->A->m : core_->A->n; }
   std::string DebugString() const override;
   std::shared_ptr<const LinearMapImpl> Transpose() const override;
   std::shared_ptr<const LinearMapImpl> Inverse() const override;
@@ -61,16 +80,23 @@ class SparseMatrixImpl final : public LinearMapImpl {  // linear/sparse_matrix_i
   void Apply(double alpha, const DVec& x, double beta, const DVec& y) const override;
   std::vector<double> AsDenseHost() const override;
 
-  const HostCsc& csc() const { return A_; }
+  // host CSC of the map itself (transposition and factor applied; materialised once when needed)
+  const HostCsc& csc() const;
+  // the same without the scalar factor (structure and unscaled values; never copies)
+  const HostCsc& csc_unscaled() const { return transposed_ ? core_->Transposed() : *core_->A; }
   DType dtype() const { return dt_; }
-  // CSR of this matrix / of its transpose (= its CSC arrays), uploaded on first use.
+  double scale() const { return scale_; }
+  std::shared_ptr<const LinearMapImpl> Scaled(double alpha) const;  // alpha * this, O(1)
+  // CSR of this map / of its transpose, UNSCALED values, uploaded on first use.
   const DeviceCsr& csr() const;
   const DeviceCsr& csr_of_transpose() const;
 
  private:
-  HostCsc A_;
+  std::shared_ptr<const SparseCore> core_;
+  bool transposed_ = false;
+  double scale_ = 1.0;
   DType dt_;
-  mutable std::shared_ptr<DeviceCsr> csr_, csr_t_;
+  mutable std::shared_ptr<const HostCsc> scaled_;  // csc() when scale_ != 1
 };
 
 // Host CSC form of any map (the reference's AsSparse(): kronecker_product_impl.cc:24-43).
