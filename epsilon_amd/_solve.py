@@ -87,6 +87,14 @@ def _blobs(d, keep):
                 keep.append(v)
                 arr[i].ptr = v.ctypes.data_as(ctypes.c_void_p)
                 arr[i].len = v.nbytes
+            elif isinstance(v, bytes):
+                # the bytes object's own buffer (no copy: a data matrix can be gigabytes; the
+                # library reads it during the call or copies what it keeps)
+                keep.append(v)
+                ref = ctypes.c_char_p(v) if len(v) else None
+                keep.append(ref)
+                arr[i].ptr = ctypes.cast(ref, ctypes.c_void_p) if ref is not None else None
+                arr[i].len = len(v)
             else:
                 buf = (ctypes.c_char * len(v)).from_buffer_copy(v) if len(v) else None
                 keep.append(buf)
