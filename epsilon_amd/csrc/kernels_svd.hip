@@ -274,10 +274,196 @@ bool LaunchSmallJacobi(const DVec& W, int64_t m, int64_t n, const DVec& V, int m
   return true;
 }
 
+// fp32 form of the on-chip kernel rebuilt around the latency of a rotation step, the same way as
+// PairEigFastKernel further down (the 121-sweep robust-PCA solve of the reference's benchmark
+// spent 188 of its 225 ms in 121 calls of the kernel above: 3.9 us per rotation step).  A group
+// of 8 lanes owns a column pair, a lane up to 16 CONSECUTIVE rows of it (16-byte LDS accesses,
+// column stride rows + 4), the columns of V are fetched together with those of W so that their
+// latency hides behind the dot products, and the 8-lane sums run on DPP row operations.  The sums
+// stay fp64 and the rotation is formed with the same correctly rounded operations as above: only
+// the order of the additions inside a dot product differs.  Rows are padded with zeros to a
+// multiple of 32 (they contribute nothing and stay zero under rotations).
+template <int CTRL> __device__ __forceinline__ double DppMoveD(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(b), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(b >> 32), CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(double, (static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+__device__ __forceinline__ double Sum8D(double v) {
+  v += DppMoveD<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += DppMoveD<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += DppMoveD<0x141>(v);  // row_half_mirror
+  return v;
+}
+
+__global__ __launch_bounds__(512) void SmallJacobiSvdFastKernel(float* Wg, int m, int n, float* Vg, int npad,
+                                                                int mp, int np, double tol, int max_sweeps,
+                                                                int warm, int* sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char small_svd_lds[];
+  const int ldw = mp + 4, ldv = np + 4;
+  float* W = reinterpret_cast<float*>(small_svd_lds);  // n columns of ldw floats
+  float* V = W + n * ldw;                              // n columns of ldv floats
+  __shared__ int rotated;
+  const int tid = threadIdx.x, nthreads = blockDim.x;
+  for (int i = tid; i < n * ldw; i += nthreads) {
+    const int c = i / ldw, r = i - c * ldw;
+    W[i] = r < m ? Wg[r + c * m] : 0.0f;
+  }
+  for (int i = tid; i < n * ldv; i += nthreads) {
+    const int c = i / ldv, r = i - c * ldv;
+    V[i] = r < n ? (warm ? Vg[r + c * n] : (r == c ? 1.0f : 0.0f)) : 0.0f;
+  }
+  const int pair = tid >> 3, sub = tid & 7;
+  const int rw4 = mp / 32, rv4 = np / 32;  // float4 per lane and column (<= 4)
+  const int ring = npad - 1;
+  int sweeps = 0;
+  for (; sweeps < max_sweeps; ++sweeps) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (int step = 0; step < ring; ++step) {
+      if (pair < npad / 2) {
+        int pp = pair - 1 + step;
+        if (pp >= ring) pp -= ring;
+        int p = pair == 0 ? 0 : 1 + pp;
+        int qq = npad - 2 - pair + step;
+        if (qq >= ring) qq -= ring;
+        int q = 1 + qq;
+        if (p < n && q < n) {  // (the dummy player of an odd tournament sits out)
+          if (p > q) {
+            const int t = p;
+            p = q;
+            q = t;
+          }
+          float4* wp = reinterpret_cast<float4*>(W + p * ldw + sub * (mp / 8));
+          float4* wq = reinterpret_cast<float4*>(W + q * ldw + sub * (mp / 8));
+          float4* vp = reinterpret_cast<float4*>(V + p * ldv + sub * (np / 8));
+          float4* vq = reinterpret_cast<float4*>(V + q * ldv + sub * (np / 8));
+          float4 x[4], y[4], u[4], w[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < rw4) {
+              x[i] = wp[i];
+              y[i] = wq[i];
+            }
+            if (i < rv4) {
+              u[i] = vp[i];
+              w[i] = vq[i];
+            }
+          }
+          double a = 0, b = 0, g = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < rw4) {
+              const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+              const float ys[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const double xd = static_cast<double>(xs[e]), yd = static_cast<double>(ys[e]);
+                a += xd * xd;
+                b += yd * yd;
+                g += xd * yd;
+              }
+            }
+          }
+          a = Sum8D(a);
+          b = Sum8D(b);
+          g = Sum8D(g);
+          // the sums are fp64; the rotation itself is formed and applied in the storage precision
+          const float gt = static_cast<float>(g), dt = static_cast<float>(b - a);
+          const float lim = static_cast<float>(tol) * (sqrtf(static_cast<float>(a)) * sqrtf(static_cast<float>(b)));
+          if (fabsf(gt) > lim && gt != 0.0f) {
+            const float zeta = dt / (2.0f * gt);
+            const float t = (zeta >= 0.0f ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+            const float c = 1.0f / sqrtf(1.0f + t * t), sn = c * t;
+            if (sub == 0) rotated = 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (i < rw4) {
+                float4 xo, yo;
+                xo.x = c * x[i].x - sn * y[i].x;
+                xo.y = c * x[i].y - sn * y[i].y;
+                xo.z = c * x[i].z - sn * y[i].z;
+                xo.w = c * x[i].w - sn * y[i].w;
+                yo.x = sn * x[i].x + c * y[i].x;
+                yo.y = sn * x[i].y + c * y[i].y;
+                yo.z = sn * x[i].z + c * y[i].z;
+                yo.w = sn * x[i].w + c * y[i].w;
+                wp[i] = xo;
+                wq[i] = yo;
+              }
+              if (i < rv4) {
+                float4 uo, wo;
+                uo.x = c * u[i].x - sn * w[i].x;
+                uo.y = c * u[i].y - sn * w[i].y;
+                uo.z = c * u[i].z - sn * w[i].z;
+                uo.w = c * u[i].w - sn * w[i].w;
+                wo.x = sn * u[i].x + c * w[i].x;
+                wo.y = sn * u[i].y + c * w[i].y;
+                wo.z = sn * u[i].z + c * w[i].z;
+                wo.w = sn * u[i].w + c * w[i].w;
+                vp[i] = uo;
+                vq[i] = wo;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const int any = rotated;
+    __syncthreads();
+    if (any == 0) break;
+  }
+  for (int i = tid; i < m * n; i += nthreads) {
+    const int c = i / m, r = i - c * m;
+    Wg[i] = W[c * ldw + r];
+  }
+  for (int i = tid; i < n * n; i += nthreads) {
+    const int c = i / n, r = i - c * n;
+    Vg[i] = V[c * ldv + r];
+  }
+  if (tid == 0) *sweeps_out = sweeps;
+}
+
+// false: shape outside the fast kernel's range (the general kernel takes it)
+bool SmallJacobiSvdFast(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, double tol,
+                        bool warm, int* sweeps) {
+  static const bool off = [] {
+    const char* e = std::getenv("EPSILON_HIP_SVD_SMALL_FAST");
+    return e && e[0] == '0';
+  }();
+  if (off || m > 128 || n > 128 || n < 2) return false;
+  const int64_t npad = n + (n & 1);
+  const int mp = static_cast<int>((m + 31) / 32 * 32), np = static_cast<int>((n + 31) / 32 * 32);
+  const size_t bytes = static_cast<size_t>(n) * (mp + 4 + np + 4) * sizeof(float);
+  if (bytes > kSmallLdsBytes) return false;
+  static const bool big_lds_ok = [] {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&SmallJacobiSvdFastKernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                               static_cast<int>(kSmallLdsBytes)) == hipSuccess;
+  }();
+  if (!big_lds_ok && bytes > 60 * 1024) return false;
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  auto out = rt.Alloc(sizeof(int));
+  int threads = static_cast<int>(((npad / 2) * 8 + 63) / 64 * 64);
+  threads = std::max(64, std::min(threads, 512));
+  hipLaunchKernelGGL(SmallJacobiSvdFastKernel, dim3(1), dim3(threads), bytes, s, W.as<float>(),
+                     static_cast<int>(m), static_cast<int>(n), V.as<float>(), static_cast<int>(npad), mp, np, tol,
+                     max_sweeps, warm ? 1 : 0, static_cast<int*>(out->p));
+  EPS_HIP(hipGetLastError());
+  EPS_HIP(hipMemcpyAsync(sweeps, out->p, sizeof(int), hipMemcpyDeviceToHost, s));
+  EPS_HIP(hipStreamSynchronize(s));
+  return true;
+}
+
 template <class T> bool SmallJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps,
                                        double tol, bool warm, int* sweeps) {
   const size_t bytes = static_cast<size_t>(m * n + n * n) * sizeof(T);
   if (bytes > kSmallLdsBytes) return false;
+  if constexpr (sizeof(T) == 4) {
+    if (SmallJacobiSvdFast(W, m, n, V, max_sweeps, tol, warm, sweeps)) return true;
+  }
   // a group of G lanes per column pair; every pair of a step has its own group
   const int64_t npad = n + (n & 1);
   // (measured at n = 100: G = 8 on 448 threads 0.208 s per 121-sweep solve, G = 16 on 832
