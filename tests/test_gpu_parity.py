@@ -1181,3 +1181,17 @@ def test_malformed_inputs_raise(solve_mod):
     # the library is still usable afterwards
     st, _ = solve_mod.solve(pb, [], sb, data)
     assert wire.SolverStatus.FromString(st).state == wire.SolverStatus.OPTIMAL
+
+
+def test_large_host_blob_upload(solve_mod, dtype):
+    """Host blobs of 16 MB and more take the pinned, multi-threaded upload (fp32 mode converts on
+    the host); smaller ones the plain copy.  y = A x for a 1500 x 2000 matrix (24 MB of float64)
+    whose entries make a dropped, repeated or misplaced stripe visible, against numpy."""
+    rng = np.random.RandomState(12)
+    m, n = 1500, 2000
+    A = rng.randn(m, n) + np.arange(m)[:, None] * 1e-3 + np.arange(n)[None, :] * 1e-2
+    x = rng.randn(n)
+    got = solve_mod.linear_map_apply(ir.dense_matrix(A), x)
+    want = A.dot(x)
+    tol = dict(rtol=1e-11, atol=1e-9) if dtype == "f64" else dict(rtol=2e-4, atol=2e-2)
+    np.testing.assert_allclose(got, want, **tol)
