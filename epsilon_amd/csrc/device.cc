@@ -247,12 +247,12 @@ namespace {
 // hipMemcpy from pageable memory is staged by the runtime on ONE host thread (~6 GB/s measured:
 // 0.33 s for the 1.9 GB of the 60000 x 4000 feature matrix), and in fp32 mode it moves twice the
 // bytes the device keeps.  Here the host threads convert (or copy) the source in stripes into two
-// pinned buffers that the DMA engine drains alternately: the conversion of one chunk runs beside
+// pinned 32 MB buffers that the DMA engine drains alternately: the conversion of one chunk runs beside
 // the transfer of the other and fp32 data crosses the link as fp32.
 struct PinnedStage {
   void* buf[2] = {nullptr, nullptr};
   hipEvent_t drained[2] = {nullptr, nullptr};
-  static constexpr size_t kBytes = size_t(64) << 20;
+  static constexpr size_t kBytes = size_t(32) << 20;
 };
 
 PinnedStage* GetPinnedStage() {
@@ -330,7 +330,9 @@ DVec DVec::FromHost(const double* src, int64_t n, DType dt) {
   DVec v = Empty(n, dt);
   if (n == 0) return v;
   Runtime& rt = Runtime::Get();
-  if (n >= (int64_t(1) << 21)) {  // 16 MB of doubles and more
+  // 64 MB of doubles and more (pinning the two buffers costs 10-70 ms once per process: a 60 MB
+  // matrix is quicker through the plain copy)
+  if (n >= (int64_t(1) << 23)) {
     const bool ok = dt == F64 ? UploadThroughPinned(v.as<double>(), src, n, rt.stream())
                               : UploadThroughPinned(v.as<float>(), src, n, rt.stream());
     if (ok) return v;

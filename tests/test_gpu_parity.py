@@ -1184,11 +1184,12 @@ def test_malformed_inputs_raise(solve_mod):
 
 
 def test_large_host_blob_upload(solve_mod, dtype):
-    """Host blobs of 16 MB and more take the pinned, multi-threaded upload (fp32 mode converts on
-    the host); smaller ones the plain copy.  y = A x for a 1500 x 2000 matrix (24 MB of float64)
-    whose entries make a dropped, repeated or misplaced stripe visible, against numpy."""
+    """Host blobs of 64 MB and more take the pinned, multi-threaded upload (fp32 mode converts on
+    the host; two 32 MB buffers, so this one needs three chunks); smaller ones the plain copy.
+    y = A x for a 3000 x 3000 matrix (72 MB of float64) whose entries make a dropped, repeated or
+    misplaced stripe visible, against numpy."""
     rng = np.random.RandomState(12)
-    m, n = 1500, 2000
+    m, n = 3000, 3000
     A = rng.randn(m, n) + np.arange(m)[:, None] * 1e-3 + np.arange(n)[None, :] * 1e-2
     x = rng.randn(n)
     got = solve_mod.linear_map_apply(ir.dense_matrix(A), x)
