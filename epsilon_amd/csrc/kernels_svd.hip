@@ -693,7 +693,7 @@ __device__ __forceinline__ void Rot4(float4& x, float4& y, float c, float s) {
 __global__ __launch_bounds__(kBlock) void PairEigFastKernel(const float* __restrict__ G, int nsplit,
                                                             int64_t split_stride, float* __restrict__ J,
                                                             int inner_sweeps, float tol, float skip_below,
-                                                            unsigned int* offmax) {
+                                                            unsigned int* offmax, int32_t* __restrict__ skip) {
   __shared__ __attribute__((aligned(16))) float A[kJN * kELd];  // column-major, stride 68
   __shared__ __attribute__((aligned(16))) float E[kJN * kELd];
   __shared__ float wmax[kBlock / 64];
@@ -728,7 +728,10 @@ __global__ __launch_bounds__(kBlock) void PairEigFastKernel(const float* __restr
   if ((t & 63) == 0) wmax[t >> 6] = mx;
   __syncthreads();
   const float m4 = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-  if (t == 0) atomicMax(offmax, __float_as_uint(m4));
+  if (t == 0) {
+    atomicMax(offmax, __float_as_uint(m4));
+    skip[blockIdx.x] = m4 <= skip_below ? 1 : 0;  // the updates of this pair are not launched into memory
+  }
   float* jj = J + static_cast<int64_t>(blockIdx.x) * kJN * kJN;
   if (m4 <= skip_below) {  // already orthogonal to working accuracy: J = I (E holds it)
     for (int q4 = t; q4 < kJN * kJN / 4; q4 += kBlock)
@@ -909,19 +912,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // whole 128-byte lines of the 64 columns.  (Tried and dropped: staging 128-row tiles through LDS
 // so that global loads run along rows in 512-byte runs - 158 us per launch against 135: two
 // workgroups per CU and a barrier per stage leave the matrix pipe idle more than the better
-// load pattern returns.)  The pairs are walked from the last to the first: the update of the
-// previous step wrote the panels in ascending order, so the most recently written ones - the
-// ones still in the 256 MB Infinity Cache - are read first (a 1-2 % effect).
+// load pattern returns.)  The pairs are walked from the last to the first (the update of the
+// previous step ran in ascending pair order: a 1-2 % Infinity Cache effect).
 __global__ __launch_bounds__(kBlock, 2) void PanelGramMfmaKernel(const float* __restrict__ W,
                                                                  int64_t rows, int64_t chunk, int64_t h,
-                                                                 float* __restrict__ G) {
+                                                                 float* __restrict__ G,
+                                                                 const int32_t* __restrict__ tab) {
   __shared__ float red[4][3][16][64];  // [wave][tile 00, 10, 11][register][lane]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c = lane & 31, kk = lane >> 5;
   const int64_t pair = h - 1 - static_cast<int64_t>(blockIdx.y);
   const int64_t split = blockIdx.x;
-  const float* col0 = W + (pair * kJN + c) * rows + split * chunk + 4 * kk;
-  const float* col1 = col0 + 32 * rows;
+  // the pair's two 32-column panels, wherever they are stored (tab: panel ids of this step's pairs)
+  const float* col0 = W + (static_cast<int64_t>(tab[2 * pair]) * kJB + c) * rows + split * chunk + 4 * kk;
+  const float* col1 = W + (static_cast<int64_t>(tab[2 * pair + 1]) * kJB + c) * rows + split * chunk + 4 * kk;
   f32x16 a00 = {0}, a10 = {0}, a11 = {0};
   const int64_t nblk = chunk / 32;  // the chunk is a multiple of 32 rows (zero-padded)
   // two register buffers used alternately (no copies: a copy of the prefetched block would make
@@ -991,15 +995,19 @@ __global__ __launch_bounds__(kBlock, 2) void PanelGramMfmaKernel(const float* __
 // push the panels of W out of the Infinity Cache before the next Gram launch re-reads them:
 // Gram 133 -> 122 us, but the non-temporal update itself 162 -> 172 us; dropped.)
 constexpr int kUpdRB = 4;  // row blocks per wave: the 64 registers of J are set up once per wave
-__global__ __launch_bounds__(kBlock, 2) void PanelUpdateMfmaKernel(float* __restrict__ dst,
-                                                                   const float* __restrict__ src,
-                                                                   int64_t rows,
+// IN PLACE: the panels never move - the round-robin tournament is a table of panel ids per step
+// (`tab`), so a pair whose rotation block is the identity (`skip`, set by the rotation solve when
+// the pair is already orthogonal to working accuracy: most pairs of the last sweeps) costs no
+// memory traffic at all, and no second copy of W and V is needed.
+__global__ __launch_bounds__(kBlock, 2) void PanelUpdateMfmaKernel(float* P, int64_t rows,
                                                                    const float* __restrict__ J,
-                                                                   const int32_t* __restrict__ dst_block) {
+                                                                   const int32_t* __restrict__ tab,
+                                                                   const int32_t* __restrict__ skip) {
   __shared__ float Js[kJN * kJLd];  // [c][k], stride 65
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, kk = lane >> 5;
   const int64_t pair = blockIdx.y;
+  if (skip[pair]) return;  // J = I
   const float* jg = J + pair * kJN * kJN;  // column-major: J[k + 64 c]
   for (int idx = t; idx < kJN * kJN; idx += kBlock) Js[(idx >> 6) * kJLd + (idx & 63)] = jg[idx];
   __syncthreads();
@@ -1014,9 +1022,8 @@ __global__ __launch_bounds__(kBlock, 2) void PanelUpdateMfmaKernel(float* __rest
   // uniform bases + one 32-bit lane offset: every access is "scalar base + lane offset", which
   // keeps the 64 addresses of a block out of the vector registers (a pair is 64 * rows floats,
   // far below 2^32 bytes)
-  const float* sbase = src + pair * kJN * rows;
-  float* dbase0 = dst + static_cast<int64_t>(dst_block[2 * pair]) * kJB * rows;
-  float* dbase1 = dst + static_cast<int64_t>(dst_block[2 * pair + 1]) * kJB * rows;
+  float* base0 = P + static_cast<int64_t>(tab[2 * pair]) * kJB * rows;      // columns 0..31 of the pair
+  float* base1 = P + static_cast<int64_t>(tab[2 * pair + 1]) * kJB * rows;  // columns 32..63
   const unsigned urows = static_cast<unsigned>(rows);
   const unsigned lin = static_cast<unsigned>(r) + static_cast<unsigned>(kk) * urows;       // loads
   const unsigned lout = static_cast<unsigned>(r) + static_cast<unsigned>(4 * kk) * urows;  // stores
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(kBlock, 2) void PanelUpdateMfmaKernel(float* __rest
   auto load = [&](float* x, int64_t blk) {
     const unsigned off = lin + static_cast<unsigned>(blk) * 32u;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) x[s] = (sbase + static_cast<int64_t>(2 * s) * rows)[off];
+    for (int s = 0; s < 32; ++s) x[s] = ((s < 16 ? base0 : base1) + static_cast<int64_t>(2 * (s & 15)) * rows)[off];
   };
   auto compute = [&](const float* x, int64_t blk, bool store) {
     f32x16 acc0 = {0}, acc1 = {0};
@@ -1040,8 +1047,8 @@ __global__ __launch_bounds__(kBlock, 2) void PanelUpdateMfmaKernel(float* __rest
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int64_t cbase = static_cast<int64_t>((g & 3) + 8 * (g >> 2)) * rows;
-      (dbase0 + cbase)[off] = acc0[g];
-      (dbase1 + cbase)[off] = acc1[g];
+      (base0 + cbase)[off] = acc0[g];
+      (base1 + cbase)[off] = acc1[g];
     }
   };
   const int64_t last = nblk - 1;  // unconditional, clamped loads (see PanelGramMfmaKernel)
@@ -1124,8 +1131,9 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
   const int64_t kchunk = ((m_ref + nsplit - 1) / nsplit + 31) / 32 * 32;
   const int64_t mp = nsplit * kchunk;
   // padded working copies
-  DVec Wp = DVec::Zeros(mp * npad, dt), Wt = DVec::Empty(mp * npad, dt);
-  DVec Vp = DVec::Zeros(npad * npad, dt), Vt = DVec::Empty(npad * npad, dt);
+  // (the matrix-core path updates in place: no second copy)
+  DVec Wp = DVec::Zeros(mp * npad, dt), Wt = kMfma ? DVec() : DVec::Empty(mp * npad, dt);
+  DVec Vp = DVec::Zeros(npad * npad, dt), Vt = kMfma ? DVec() : DVec::Empty(npad * npad, dt);
   if (m > 0)
     EPS_HIP(hipMemcpy2DAsync(Wp.data(), mp * sizeof(T), W.data(), m * sizeof(T), m * sizeof(T), n,
                              hipMemcpyDeviceToDevice, s));
@@ -1160,6 +1168,28 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
   std::vector<int32_t> block_at(nb);  // original block id at each position
   for (int64_t i = 0; i < nb; ++i) block_at[i] = static_cast<int32_t>(i);
   const int64_t steps = nb - 1;
+  // matrix-core path: the panels stay where they are; the tournament is a table of the panel ids
+  // at the positions [top_0 bot_0 top_1 bot_1 ...] of every step (after nb - 1 steps the
+  // arrangement is the initial one again, so one table serves every sweep)
+  std::shared_ptr<Buffer> tab_buf, skip_buf;
+  const int32_t* tab_dev = nullptr;
+  int32_t* skip_dev = nullptr;
+  if constexpr (kMfma) {
+    std::vector<int32_t> tab(static_cast<size_t>(steps * nb)), at(nb), next(nb);
+    for (int64_t i = 0; i < nb; ++i) at[i] = static_cast<int32_t>(i);
+    for (int64_t st = 0; st < steps; ++st) {
+      std::copy(at.begin(), at.end(), tab.begin() + st * nb);
+      for (int64_t i = 0; i < nb; ++i) next[dst[i]] = at[i];
+      at.swap(next);
+    }
+    for (int64_t i = 0; i < nb; ++i) EPS_CHECK(at[i] == static_cast<int32_t>(i));
+    tab_buf = rt.Alloc(tab.size() * sizeof(int32_t));
+    EPS_HIP(hipMemcpyAsync(tab_buf->p, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    EPS_HIP(hipStreamSynchronize(s));
+    tab_dev = static_cast<const int32_t*>(tab_buf->p);
+    skip_buf = rt.Alloc(static_cast<size_t>(h) * sizeof(int32_t));
+    skip_dev = static_cast<int32_t*>(skip_buf->p);
+  }
   static const char* inner_env = std::getenv("EPSILON_HIP_SVD_INNER");  // tuning knob
   // one inner sweep per step: measured 7-18 % faster than two, cold and warm-started, at n = 2048
   // and 4096 (three is slower still); the outer iteration absorbs what an inner sweep leaves
@@ -1174,7 +1204,7 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
       if constexpr (kMfma) {
         const dim3 gg(static_cast<unsigned>(nsplit), static_cast<unsigned>(h));
         hipLaunchKernelGGL(PanelGramMfmaKernel, gg, dim3(kBlock), 0, s, Wp.as<float>(), mp, kchunk, h,
-                           G.as<float>());
+                           G.as<float>(), tab_dev + step * nb);
       } else if (mp >= 3072) {
         const dim3 gg(static_cast<unsigned>(nsplit), static_cast<unsigned>(h));
         hipLaunchKernelGGL(PanelGramKernel<T>, gg, dim3(kBlock), 0, s, Wp.as<T>(), mp, kchunk, h, G.as<T>());
@@ -1186,7 +1216,7 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
       if constexpr (kMfma) {
         hipLaunchKernelGGL(PairEigFastKernel, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
                            G.as<float>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<float>(), inner,
-                           static_cast<float>(tol), static_cast<float>(done_tol), offmax);
+                           static_cast<float>(tol), static_cast<float>(done_tol), offmax, skip_dev);
       } else {
         hipLaunchKernelGGL(PairEigKernel<T>, dim3(static_cast<unsigned>(h)), dim3(kBlock), 0, s,
                            G.as<T>(), static_cast<int>(nsplit), h * kJN * kJN, J.as<T>(), inner, tol,
@@ -1194,13 +1224,11 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
       }
       if constexpr (kMfma) {
         const dim3 gw(static_cast<unsigned>((mp / 32 + 4 * kUpdRB - 1) / (4 * kUpdRB)), static_cast<unsigned>(h));
-        hipLaunchKernelGGL(PanelUpdateMfmaKernel, gw, dim3(kBlock), 0, s, Wt.as<float>(), Wp.as<float>(), mp,
-                           J.as<float>(), dst_dev);
+        hipLaunchKernelGGL(PanelUpdateMfmaKernel, gw, dim3(kBlock), 0, s, Wp.as<float>(), mp, J.as<float>(),
+                           tab_dev + step * nb, skip_dev);
         const dim3 gv(static_cast<unsigned>((npad / 32 + 4 * kUpdRB - 1) / (4 * kUpdRB)), static_cast<unsigned>(h));
-        hipLaunchKernelGGL(PanelUpdateMfmaKernel, gv, dim3(kBlock), 0, s, Vt.as<float>(), Vp.as<float>(), npad,
-                           J.as<float>(), dst_dev);
-        std::swap(Wp, Wt);
-        std::swap(Vp, Vt);
+        hipLaunchKernelGGL(PanelUpdateMfmaKernel, gv, dim3(kBlock), 0, s, Vp.as<float>(), npad, J.as<float>(),
+                           tab_dev + step * nb, skip_dev);
       } else if (mp >= 3072) {
         // P <- P J with the panels' move folded in (Wt / Vt receive the new layout, then swap);
         // a thread per row needs thousands of rows to fill the chip (n = 2048: slower than the
@@ -1227,9 +1255,11 @@ int BlockJacobiImpl(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_
         hipLaunchKernelGGL(PermuteBlocksKernel<T>, gv, dim3(kBlock), 0, s, Vp.as<T>(), Vt.as<T>(),
                            npad, dst_dev);
       }
-      std::vector<int32_t> next(nb);
-      for (int64_t i = 0; i < nb; ++i) next[dst[i]] = block_at[i];
-      block_at.swap(next);
+      if constexpr (!kMfma) {  // (the panels of the matrix-core path never move)
+        std::vector<int32_t> next(nb);
+        for (int64_t i = 0; i < nb; ++i) next[dst[i]] = block_at[i];
+        block_at.swap(next);
+      }
     }
     unsigned int bits = 0;
     EPS_HIP(hipMemcpyAsync(&bits, offmax, sizeof(bits), hipMemcpyDeviceToHost, s));
