@@ -735,6 +735,31 @@ int eps_bench_svd(int64_t m, int64_t n, int rank, int max_sweeps, double perturb
   });
 }
 
+int eps_bench_svd_device(const void* y_dev, int64_t m, int64_t n, int max_sweeps, double* ms, int* sweeps) {
+  return Guard([&] {
+    EPS_CHECK(y_dev != nullptr && m > 0 && n > 0 && ms != nullptr);
+    Runtime& rt = Runtime::Get();
+    EPS_HIP(hipDeviceSynchronize());  // the caller's stream may still be writing the matrix
+    DVec Y = DVec::Borrow(const_cast<void*>(y_dev), m * n, F32);
+    DVec W = Y.Clone();
+    DVec V = DVec::Empty(n * n, F32);
+    rt.Sync();
+    hipEvent_t a, b;
+    EPS_HIP(hipEventCreate(&a));
+    EPS_HIP(hipEventCreate(&b));
+    EPS_HIP(hipEventRecord(a, rt.stream()));
+    const int sw = k::JacobiSvd(W, m, n, V, max_sweeps, false, false);
+    EPS_HIP(hipEventRecord(b, rt.stream()));
+    EPS_HIP(hipEventSynchronize(b));
+    float e = 0;
+    EPS_HIP(hipEventElapsedTime(&e, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms = e;
+    if (sweeps) *sweeps = sw;
+  });
+}
+
 int eps_tv1d(const double* v, size_t n, double lam, double* x) {
   return Guard([&] {
     const DType dt = ConfiguredDType();

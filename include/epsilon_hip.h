@@ -232,6 +232,9 @@ int eps_bench_prox(int kind, int64_t n, int iters, double* ms_avg);
 int eps_bench_svd(int64_t m, int64_t n, int rank, int max_sweeps, double perturb, double* ms_cold,
                   int* sweeps_cold, double* ms_warm, int* sweeps_warm, double* defects);
 
+/* The same decomposition (cold) of a caller-provided m x n column-major float32 matrix in HBM. */
+int eps_bench_svd_device(const void* y_dev, int64_t m, int64_t n, int max_sweeps, double* ms, int* sweeps);
+
 /* Exact 1-D total-variation prox of v (n float64) with weight lam
  * (reference prox/total_variation_1d.cc:21 -> glmgen tf_dp). */
 int eps_tv1d(const double* v, size_t n, double lam, double* x);
