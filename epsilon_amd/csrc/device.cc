@@ -1,6 +1,8 @@
 #include "device.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -307,21 +309,36 @@ template <class D> void ParallelConvert(D* dst, const double* src, int64_t len) 
 
 // false: the pinned buffers are not available (the caller takes the plain route)
 template <class D> bool UploadThroughPinned(D* dev, const double* src, int64_t n, hipStream_t s) {
+  const auto tp = std::chrono::steady_clock::now();
   PinnedStage* st = GetPinnedStage();
   if (st == nullptr) return false;
+  const double pin_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count();
   const int64_t chunk = static_cast<int64_t>(PinnedStage::kBytes / sizeof(D));
   int which = 0;
   bool used[2] = {false, false};
+  static const bool trace = [] {
+    const char* e = std::getenv("EPSILON_HIP_INIT_TRACE");
+    return e && e[0] == '2';
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  double conv_ms = 0;
   for (int64_t off = 0; off < n; off += chunk, which ^= 1) {
     const int64_t len = std::min(chunk, n - off);
     if (used[which]) EPS_HIP(hipEventSynchronize(st->drained[which]));
+    const auto c0 = std::chrono::steady_clock::now();
     ParallelConvert(static_cast<D*>(st->buf[which]), src + off, len);
+    conv_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
     EPS_HIP(hipMemcpyAsync(dev + off, st->buf[which], static_cast<size_t>(len) * sizeof(D),
                            hipMemcpyHostToDevice, s));
     EPS_HIP(hipEventRecord(st->drained[which], s));
     used[which] = true;
   }
   EPS_HIP(hipStreamSynchronize(s));
+  if (trace)
+    std::fprintf(stderr, "[host] pinned upload %lld elements: pinned buffers ready after %.2f ms; %.2f ms (host convert / copy %.2f ms, %d threads)\n",
+                 static_cast<long long>(n), pin_ms,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), conv_ms,
+                 HostThreads());
   return true;
 }
 }  // namespace
@@ -332,7 +349,11 @@ DVec DVec::FromHost(const double* src, int64_t n, DType dt) {
   Runtime& rt = Runtime::Get();
   // 64 MB of doubles and more (pinning the two buffers costs 10-70 ms once per process: a 60 MB
   // matrix is quicker through the plain copy)
-  if (n >= (int64_t(1) << 23)) {
+  static const bool pinned_on = [] {
+    const char* e = std::getenv("EPSILON_HIP_PINNED_UPLOAD");
+    return !(e && e[0] == '0');
+  }();
+  if (pinned_on && n >= (int64_t(1) << 23)) {
     const bool ok = dt == F64 ? UploadThroughPinned(v.as<double>(), src, n, rt.stream())
                               : UploadThroughPinned(v.as<float>(), src, n, rt.stream());
     if (ok) return v;

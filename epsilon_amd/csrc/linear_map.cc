@@ -1,5 +1,9 @@
 #include "linear_map.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -90,14 +94,23 @@ DVec DataMap::DenseDevice(const pb::Constant& c_in) {
     EPS_CHECK_MSG(b.len == static_cast<size_t>(count) * sizeof(double),
                   "dense blob '" << c.data_location << "' has " << b.len << " bytes, expected "
                                  << count * sizeof(double));
+    static const bool trace = [] {
+      const char* e = std::getenv("EPSILON_HIP_INIT_TRACE");
+      return e && std::atoi(e) >= 2;
+    }();
+    auto now = [] {
+      return std::chrono::duration<double, std::milli>(
+                 std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t0 = trace ? now() : 0;
     v = DVec::FromHost(static_cast<const double*>(b.ptr), count, dtype_);
-    // a large owned copy has served its purpose once the matrix is resident in HBM
-    // (DenseHost falls back to the device copy)
-    if (b.owned && b.len >= (64u << 20)) {  // (FromHost has synchronised)
-      Blob& mb = blobs_[c.data_location];
-      mb.owned.reset();
-      mb.ptr = nullptr;
-    }
+    const double t1 = trace ? now() : 0;
+    // (the owned host copy of a solver handle stays until the handle goes: unmapping it here cost
+    // 33 ms of Init for the 376 MB MNIST matrix, on this thread or - through the address-space
+    // lock - on a helper thread alike)
+    if (trace && count >= (1 << 20))
+      std::fprintf(stderr, "[host] dense '%s' %lld elements: to device %.2f ms\n",
+                   c.data_location.c_str(), static_cast<long long>(count), t1 - t0);
   } else {
     const DType bdt = b.kind == 1 ? F32 : F64;
     EPS_CHECK_MSG(b.len == static_cast<size_t>(count),
