@@ -27,6 +27,7 @@ DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_gemv_multi.hip", []),
                   ("kernels_gemm.hip", []),
                   ("kernels_gemm_f16split.hip", []),
+                  ("kernels_gemm_f64.hip", []),
                   ("kernels_factor.hip", []),
                   ("kernels_sparse.hip", []),
                   ("kernels_segprox.hip", ["-ffp-contract=off"]),

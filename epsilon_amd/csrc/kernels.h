@@ -110,6 +110,13 @@ void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc);
 bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A,
                   int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C, int64_t ldc,
                   bool lower_only);
+// fp64 products on the software-pipelined f64 MFMA kernel (kernels_gemm_f64.hip), arguments as
+// GemmBatched (n1 = inner batch count, batch = n1 * outer); false if the operands are not
+// 16-byte aligned (nothing is done).
+bool GemmF64Pipe(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A,
+                 int64_t lda, int64_t sA, const DVec& B, int64_t ldb, int64_t sB, double beta,
+                 const DVec& C, int64_t ldc, int64_t sC, int64_t n1, int64_t batch, bool lower_only,
+                 int64_t sA2, int64_t sB2);
 // C (M x N, ldc == M, N <= 16) = alpha op(A) B + beta C as a mat-vec with N right-hand sides
 // (kernels_gemv_multi.hip); false if the shape / alignment is not covered (nothing is done).
 bool MultiGemv(bool transA, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,

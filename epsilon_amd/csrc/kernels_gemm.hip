@@ -11,7 +11,8 @@
 //    The accumulator is produced transposed (MFMA "A" operand <- B tile) so that a register's
 //    32 lanes hit 32 consecutive rows of column-major C: 128-byte coalesced stores.
 //  * GemmGeneric<T>: 64x64 LDS-tiled VALU kernel for f64 and for small shapes.
-//  * GemmMfmaF64: the f32 tile on v_mfma_f64_16x16x4_f64, opt-in (slower than the VALU kernel today).
+//  * GemmMfmaF64: the f32 tile on v_mfma_f64_16x16x4_f64, unpipelined (EPSILON_HIP_GEMM=mfma_simple);
+//    the fp64 mode's products run on the pipelined kernel of kernels_gemm_f64.hip.
 //
 // `lower_only` skips tiles strictly above the diagonal (SYRK-style, half the flops).
 #include <hip/hip_runtime.h>
@@ -741,10 +742,14 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                        lower_only ? 1 : 0, sA, sB, sC, n1, sA2, sB2);
     return;
   }
-  // fp64: MI355X's f64 matrix peak equals its f64 vector peak (78.6 TFLOP/s), and this plain
-  // (unpipelined) MFMA kernel measured 19.4 TFLOP/s on 4096^3 against 28.9 for the VALU tile
-  // kernel below - so the VALU kernel stays the default and the MFMA one is opt-in
-  // (EPSILON_HIP_GEMM=mfma; kept under test for the day it is pipelined like the f32 one).
+  // fp64: the software-pipelined MFMA kernel (kernels_gemm_f64.hip) for everything with at least
+  // half a tile of output; the plain MFMA kernel below it (19.4 TFLOP/s on 4096^3, against 28.9
+  // for the VALU tile kernel) is kept as EPSILON_HIP_GEMM=mfma_simple and for unaligned operands
+  // of EPSILON_HIP_GEMM=mfma.
+  if (A.dt == F64 && mode != 1 && mode != 3 && (mode == 2 || (M >= 64 && N >= 64 && K >= 32)) &&
+      GemmF64Pipe(transA, transB, M, N, K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, n1, batch,
+                  lower_only, sA2, sB2))
+    return;
   if (A.dt == F64 && mode >= 2) {
     dim3 grid(static_cast<unsigned>((M + MT - 1) / MT), static_cast<unsigned>((N + MT - 1) / MT),
               static_cast<unsigned>(batch));

@@ -304,14 +304,20 @@ def test_gemm_f16_split_general_and_inverse(solve_mod):
     assert np.abs(W - np.linalg.inv(Mx)).max() < 1e-5 * np.abs(np.linalg.inv(Mx)).max() + 1e-6
 
 
-def test_gemm_f64_mfma_vs_numpy(solve_mod):
-    """Dense*Dense in fp64 on v_mfma_f64_16x16x4_f64 (opt-in kernel; its accumulator map is NOT the
-    f32 one): all four transpose combinations, ragged edges, asymmetric operands, SYRK."""
+@pytest.mark.parametrize("mode", ["mfma", "mfma_simple", "auto"])
+def test_gemm_f64_mfma_vs_numpy(solve_mod, mode):
+    """Dense*Dense in fp64 on v_mfma_f64_16x16x4_f64 (its accumulator map is NOT the f32 one): all
+    four transpose combinations, ragged edges, asymmetric operands, SYRK.  "mfma" / "auto": the
+    software-pipelined kernel (kernels_gemm_f64.hip) where the operands allow 16-byte loads - even
+    leading dimensions: edge tiles shifted back to the matrix edge (even sizes) or bounds-checked
+    (odd sizes, sizes below one tile) - and the plain MFMA kernel ("mfma") or the VALU kernel
+    ("auto") elsewhere; "mfma_simple": the plain MFMA kernel everywhere."""
     solve_mod.set_option("dtype", "f64")
-    solve_mod.set_option("gemm", "mfma")
+    solve_mod.set_option("gemm", mode)
     try:
         rng = np.random.RandomState(12)
-        for (m, k, n) in [(300, 500, 260), (128, 64, 128), (129, 33, 65), (64, 16, 64), (257, 19, 130)]:
+        for (m, k, n) in [(300, 500, 260), (128, 64, 128), (129, 33, 65), (64, 16, 64), (257, 19, 130),
+                          (386, 1030, 258), (130, 72, 66), (512, 40, 384)]:
             for ta in (False, True):
                 for tb in (False, True):
                     A = rng.randn(*((k, m) if ta else (m, k))) + np.arange(m)[None if ta else slice(None), None if not ta else slice(None)] * 0.01
@@ -319,10 +325,18 @@ def test_gemm_f64_mfma_vs_numpy(solve_mod):
                     _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), ta, tb)
                     ref = (A.T if ta else A).dot(B.T if tb else B)
                     np.testing.assert_allclose(C, ref, rtol=1e-12, atol=1e-11)
-        A = rng.randn(200, 700)
-        Am = ir.dense_matrix(A)
-        _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
-        np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-12, atol=1e-11)
+        for shape in [(200, 700), (1100, 264)]:  # (1100: 45 lower tiles on the compact grid)
+            A = rng.randn(*shape)
+            Am = ir.dense_matrix(A)
+            _, C = solve_mod.linear_map_binary("*", Am, Am, False, True)
+            np.testing.assert_allclose(C, A.dot(A.T), rtol=1e-12, atol=1e-11)
+            assert np.array_equal(C, C.T)
+        # the blocked Cholesky inverse: batched products with strides
+        nn = 1500
+        Q = rng.randn(nn, 40)
+        Mx = np.eye(nn) + 2 * Q.dot(Q.T)
+        W = solve_mod.linear_map_inverse(ir.dense_matrix(Mx))
+        assert np.abs(W.dot(Mx) - np.eye(nn)).max() < 1e-10
     finally:
         solve_mod.set_option("gemm", "auto")
         solve_mod.set_option("dtype", "f32")

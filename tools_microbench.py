@@ -105,6 +105,19 @@ if __name__ == "__main__":
         gemm(0, 1, 4096, 4096, 4096, iters=5)
         gemm(0, 0, 4096, 4096, 4096, iters=5)
         gemm(1, 0, 4096, 4096, 4096, iters=5)
+    if "gemm64" in what:
+        for mode in ("auto", "generic", "mfma_simple"):
+            _solve.set_option("gemm", mode)
+            print("EPSILON_HIP_GEMM=%s" % mode, flush=True)
+            gemm(0, 1, 4096, 4096, 4096, iters=3, dtype="f64")
+            gemm(0, 0, 4096, 4096, 4096, iters=3, dtype="f64")
+            gemm(1, 0, 4096, 4096, 4096, iters=3, dtype="f64")
+            gemm(1, 1, 4096, 4096, 4096, iters=3, dtype="f64")
+            if mode != "mfma_simple":
+                gemm(0, 1, 10000, 10000, 50000, lower=1, iters=1, dtype="f64")
+        _solve.set_option("gemm", "auto")
+        inverse(10000, iters=1, dtype="f64")
+        _solve.set_option("dtype", "f32")
     if "syrk" in what:
         gemm(0, 1, 10000, 10000, 50000, lower=2, iters=2)
     if "inverse1" in what:
