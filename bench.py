@@ -380,9 +380,9 @@ def main():
             flops = float(m) * (m + 1) * At.shape[0]  # lower triangle incl. diagonal, 2 flops / MAC
             out["init_breakdown"] = {
                 "gram_syrk_ms": gram_ms,
-                "gram": {"bound": "mfma" if args.dtype == "f32" else "valu",
+                "gram": {"bound": "mfma",
                          "kernel": ("GemmMfmaF32PipeKernel<true,true> (SYRK A A^T, lower tiles)" if args.dtype == "f32"
-                                    else "GemmGenericKernel<double> (SYRK A A^T, lower tiles; fp64 VALU)"),
+                                    else "GemmMfmaF64PipeKernel<true,true> (SYRK A A^T, lower tiles; v_mfma_f64_16x16x4_f64)"),
                          "achieved": flops / (gram_ms * 1e-3) / 1e12,
                          "peak": 157.3 if args.dtype == "f32" else 78.6, "unit": "TFLOP/s",
                          "frac": flops / (gram_ms * 1e-3) / 1e12 / (157.3 if args.dtype == "f32" else 78.6),
