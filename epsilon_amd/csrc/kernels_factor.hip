@@ -264,10 +264,13 @@ __global__ __launch_bounds__(256) void PotrfPanelStepKernel(T* W, int64_t ld, in
 // block itself (the same instructions on the same data: identical bits) next to its own rows'
 // update - the panel columns it stages serve both - so the 157 steps of a 10^4 matrix are one
 // launch each and the single-workgroup diagonal kernel leaves the critical path.  Workgroup 0
-// writes the factor of the diagonal block back.  (fp64 keeps the two kernels: the third 64 x 64
-// tile does not fit the 64 KB of static LDS.)
+// writes the factor of the diagonal block to a side buffer (nothing later in the factorisation
+// reads a diagonal block; writing it into W here would race with the workgroups of the same
+// launch that have yet to read the unfactored block).  (fp64 keeps the two kernels: the third
+// 64 x 64 tile does not fit the 64 KB of static LDS.)
 __global__ __launch_bounds__(256) void PotrfFusedStepKernel(float* W, int64_t ld, int64_t n, int64_t K0,
-                                                            int64_t k0, int kb, int* flag) {
+                                                            int64_t k0, int kb, int* flag,
+                                                            float* __restrict__ dfac) {
   using T = float;
   __shared__ T Tt[NB][NB];        // [column][row], this workgroup's rows
   __shared__ T Dd[NB][NB];        // [column][row], the diagonal block
@@ -339,7 +342,9 @@ __global__ __launch_bounds__(256) void PotrfFusedStepKernel(float* W, int64_t ld
     StaticFor<0, NB>::Run([&](auto cc) {
       constexpr int c = decltype(cc)::value;
       buf[r * NB + c] = rowv[c];  // zero above the diagonal by construction
-      if (blockIdx.x == 0 && r < kb && c < kb && r >= c) W[(k0 + r) + (k0 + c) * ld] = rowv[c];
+      // NOT into W: the other workgroups of this launch read the unfactored block from there,
+      // whenever they happen to start (PotrfBlocked scatters the side buffer at the end)
+      if (blockIdx.x == 0) dfac[c * NB + r] = rowv[c];
     });
   }
   __syncthreads();
@@ -586,6 +591,12 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
     // rows below it (same update + forward substitution against the new L11) - instead of the
     // diagonal kernel, a copy and two small GEMMs; the 64 x 64 inverses the later stages want are
     // formed for all blocks at once at the end.
+    static const bool two_kernels = std::getenv("EPSILON_HIP_POTRF_TWO_KERNELS") != nullptr;
+    const unsigned nblk = static_cast<unsigned>((n + NB - 1) / NB);
+    const bool fused = dt == F32 && !two_kernels;
+    std::shared_ptr<Buffer> dfac_buf;
+    if (fused) dfac_buf = rt.Alloc(static_cast<size_t>(nblk) * NB * NB * sizeof(float));
+    float* dfac = fused ? static_cast<float*>(dfac_buf->p) : nullptr;
     for (int64_t K0 = 0; K0 < n; K0 += OB) {
       const int64_t KB = std::min<int64_t>(OB, n - K0);
       for (int64_t k0 = K0; k0 < K0 + KB; k0 += NB) {
@@ -593,10 +604,9 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
         const int64_t rem = n - (k0 + kb);
         const unsigned blocks = static_cast<unsigned>((rem + NB - 1) / NB);
         if (dt == F32) {
-          static const bool two_kernels = std::getenv("EPSILON_HIP_POTRF_TWO_KERNELS") != nullptr;
-          if (!two_kernels) {
+          if (fused) {
             hipLaunchKernelGGL(PotrfFusedStepKernel, dim3(blocks ? blocks : 1), dim3(256), 0, s,
-                               W.as<float>(), ld, n, K0, k0, kb, flag);
+                               W.as<float>(), ld, n, K0, k0, kb, flag, dfac + (k0 / NB) * NB * NB);
           } else {
             hipLaunchKernelGGL(PotrfDiagStepKernel<float>, dim3(1), dim3(256), 0, s, W.as<float>(), ld,
                                K0, k0, kb, flag);
@@ -619,7 +629,8 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
         Gemm(false, true, rem2, rem2, KB, -1.0, L21, ld, L21, ld, 1.0, W22, ld, true);
       }
     }
-    const unsigned nblk = static_cast<unsigned>((n + NB - 1) / NB);
+    if (fused)  // the factors of the diagonal blocks, from the side buffer (zeros above the diagonal)
+      hipLaunchKernelGGL(ScatterDiagBlocksKernel<float>, dim3(nblk), dim3(256), 0, s, dfac, W.as<float>(), ld, n);
     if (dt == F32)
       hipLaunchKernelGGL(TrtriDiagBlocksKernel<float>, dim3(nblk), dim3(64), 0, s, W.as<float>(), ld, n,
                          dinv.as<float>());
