@@ -4,6 +4,7 @@
 // reference's plugin interface (prox/prox.h:37-77) and cites the file it restates; the numeric
 // work is in kernels_segprox.hip / kernels_svd.hip.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "comm.h"
@@ -306,6 +307,7 @@ class OrthoInvariantProx : public VectorProx {
     const char* pe = std::getenv("EPSILON_HIP_SVD_PARTIAL");
     partial_enabled_ = !(pe && pe[0] == '0');
     partial_backoff_ = 0;
+    partial_fail_streak_ = 0;
     last_rank_ = -1;
   }
 
@@ -329,11 +331,23 @@ class OrthoInvariantProx : public VectorProx {
         --partial_backoff_;
       } else {
         DVec X;
-        if (ThresholdedPartialSvd(y, input.lambda(), &X)) {
+        static const bool trace = std::getenv("EPSILON_HIP_SVD_TRACE") != nullptr;
+        const bool ok = ThresholdedPartialSvd(y, input.lambda(), &X);
+        if (trace)
+          std::fprintf(stderr, "[svd] call %lld: partial route %s (values above lambda: %lld)\n",
+                       static_cast<long long>(calls_), ok ? "taken" : "gave up", static_cast<long long>(last_rank_));
+        if (ok) {
+          partial_fail_streak_ = 0;
           output->set_value(0, X);
           return;
         }
-        partial_backoff_ = 16;  // the spectrum is (numerically) full above lambda: stop trying for a while
+        // The spectrum is (numerically) full above lambda: stop trying for a while.  A failed
+        // attempt costs a few per cent of the full decomposition, and the first applications of
+        // an ADMM run (an argument far from its low-rank limit) say little about the later ones:
+        // skip 1, 2, 4 ... 16 applications after consecutive failures.
+        partial_backoff_ = std::min(16, 1 << std::min(partial_fail_streak_, 4));
+        if (const char* e = std::getenv("EPSILON_HIP_SVD_PARTIAL_BACKOFF")) partial_backoff_ = std::atoi(e);
+        ++partial_fail_streak_;
       }
     }
     DVec W, R;
@@ -620,6 +634,7 @@ class OrthoInvariantProx : public VectorProx {
   static constexpr int64_t kPartialMinSize = 512;
   bool partial_enabled_ = true;
   int partial_backoff_ = 0;   // applications left before the partial route is tried again
+  int partial_fail_streak_ = 0;
   int64_t last_rank_ = -1;    // singular values above lambda at the last successful partial call
 };
 
