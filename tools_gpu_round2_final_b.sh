@@ -1,11 +1,8 @@
 #!/bin/bash
-# round-2 final evidence: full GPU suite, bench + rocprof, slab rehearsal gaps, TV profile,
-# microbenchmarks, config-5 (SVD / robust PCA / nuclear-norm prox) evidence
+# round-2 final evidence, part 2: slab rehearsal gaps, TV profile, microbenchmarks, config-5 evidence, suite
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -q -m gpu -x > gpurun_out/final_gpu_suite.log 2>&1; echo "suite rc=$?"; tail -3 gpurun_out/final_gpu_suite.log
-bash tools_profile.sh > gpurun_out/final_profile.log 2>&1; echo "profile rc=$?"
 bash tools_profile_slab.sh > gpurun_out/final_slab.log 2>&1; echo "slab rc=$?"
 bash tools_profile_tv1d.sh > gpurun_out/final_tv.log 2>&1; echo "tv rc=$?"
 python tools_microbench.py prox > gpurun_out/final_prox.jsonl 2> gpurun_out/final_prox.err; echo "prox rc=$?"
