@@ -191,3 +191,52 @@ def test_nuclear_norm_prox_full_size(solve_mod):
     assert abs(inner - nuc) <= 2e-3 * nuc, (inner, nuc)
     del X, Y, P, Q, B
     torch.cuda.empty_cache()
+
+
+def test_multiclass_hinge_full_size(solve_mod):
+    """configs[3] at its full size (X 60000 x 784, k = 10, lam = 1; reference
+    docs/notebooks/mnist.rst:88-129) on a learnable synthetic instance - labels planted by a random
+    linear classifier - checked without the oracle (hours at this size):
+      * the fp32 and the fp64 mode (different GEMM / mat-vec / contraction kernels) stop after
+        the same sweeps at the same point;
+      * permuting the samples (the rows of X and Y: every long contraction sums in another
+        order, the sample-indexed variables move) returns the same Theta;
+      * the objective, re-evaluated on the host in fp64, beats Theta = 0 and the planted
+        classifier is learned (training accuracy far above the 10 % of chance)."""
+    from epsilon_amd import problems
+    m, nf, k, lam = 60000, 784, 10, 1.0
+    rng = np.random.RandomState(3)
+    X = rng.rand(m, nf)
+    T0 = rng.randn(nf, k)
+    lab = (X - 0.5).dot(T0).argmax(axis=1)
+    Y = np.zeros((m, k))
+    Y[np.arange(m), lab] = 1.0
+    params = wire.SolverParams(max_iterations=3000).SerializeToString()
+
+    def solve(Xs, Ys, dt):
+        solve_mod.set_option("dtype", dt)
+        prob, _ = problems.multiclass_hinge(Xs, Ys, lam)
+        st, x = solve_mod.solve(prob.SerializeToString(), [], params, prob.expression_data())
+        st = wire.SolverStatus.FromString(st)
+        assert st.state == wire.SolverStatus.OPTIMAL
+        return st, np.frombuffer(x["var:Theta"]).reshape(nf, k, order="F").copy()
+
+    try:
+        s32, T32 = solve(X, Y, "f32")
+        s64, T64 = solve(X, Y, "f64")
+        perm = rng.permutation(m)
+        s32p, T32p = solve(X[perm], Y[perm], "f32")
+    finally:
+        solve_mod.set_option("dtype", "f32")
+    scale = np.abs(T64).max()
+    assert s32.num_iterations == s64.num_iterations == s32p.num_iterations, \
+        (s32.num_iterations, s64.num_iterations, s32p.num_iterations)
+    assert np.abs(T32 - T64).max() <= 2e-3 * scale, (np.abs(T32 - T64).max(), scale)
+    assert np.abs(T32p - T32).max() <= 2e-3 * scale, (np.abs(T32p - T32).max(), scale)
+    f_star = problems.multiclass_hinge_objective(X, Y, lam, T64)
+    f_zero = problems.multiclass_hinge_objective(X, Y, lam, np.zeros((nf, k)))
+    assert f_star < 0.9 * f_zero, (f_star, f_zero)
+    f32 = problems.multiclass_hinge_objective(X, Y, lam, T32)
+    assert abs(f32 - f_star) <= 1e-3 * abs(f_star), (f32, f_star)
+    acc = float((X.dot(T64).argmax(axis=1) == lab).mean())
+    assert acc > 0.5, acc
