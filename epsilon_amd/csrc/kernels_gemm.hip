@@ -435,24 +435,36 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF32PipeKernel(
   for (; kt + 2 < nfull; ++kt) slab(std::true_type(), kt);
   for (; kt < nk; ++kt) slab(std::false_type(), kt);
 
+  // beta != 0: the 16 old values of a block are loaded as one independent batch (clamped
+  // addresses) before the block's stores - interleaved with the stores through a pointer that
+  // may alias them, every load waited for the store before it, and a short contraction (the
+  // rank-256 updates of the Cholesky) spent most of its time in this epilogue.
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int64_t i = li0 + wi * 64 + a * 32 + l31;
-    if (i < i0 || i >= M) continue;
+    const bool i_ok = i >= i0 && i < M;
+    const int64_t ic = i < M ? i : M - 1;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
+      float old[16];
+      if (P == nullptr && beta != 0.0f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t j = lj0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          old[r] = C[ic + (j < N ? j : N - 1) * ldc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t j = lj0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (j < j0 || j >= N) continue;
+        if (!i_ok || j < j0 || j >= N) continue;
         if (P != nullptr) {
           P[(static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (MT * MT) + (i - i0) +
             (j - j0) * MT] = acc[a][b][r];
           continue;
         }
-        float* c = C + i + j * ldc;
         const float v = alpha * acc[a][b][r];
-        *c = (beta == 0.0f) ? v : v + beta * (*c);
+        C[i + j * ldc] = (beta == 0.0f) ? v : v + beta * old[r];
       }
     }
   }

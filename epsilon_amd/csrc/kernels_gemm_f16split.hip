@@ -66,6 +66,17 @@ __global__ __launch_bounds__(256) void RowAbsMaxKernel(const float* __restrict__
   atomicMax(rowmax_bits + i, __float_as_uint(mx));
 }
 
+// 1 / SplitScale (a power of two: exact), without the division
+__device__ inline float SplitScaleInv(unsigned amax_bits) {
+  const float amax = __uint_as_float(amax_bits);
+  if (!(amax > 0.0f) || !isfinite(amax)) return 1.0f;
+  int e;
+  frexpf(amax, &e);
+  int se = 11 - e;
+  if (se > 120) se = 120;
+  return ldexpf(1.0f, -se);
+}
+
 __device__ inline float SplitScale(unsigned amax_bits) {
   const float amax = __uint_as_float(amax_bits);
   if (!(amax > 0.0f) || !isfinite(amax)) return 1.0f;
@@ -262,25 +273,53 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
     }
   }
 
-  // undo the row scales: the accumulator holds s_i s_j (X_a X_b^T)_ij; 1 / s is a power of two
+  // raw partial tile of a split-K tail: scales and beta are the fix-up kernel's
+  if (P != nullptr) {
+    float* pt = P + (static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (TS * TS);
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int64_t i = i0 + wi * 128 + a * 32 + l31;
-    const float ui = (P == nullptr && i < M) ? 1.0f / SplitScale(oa.rowmax[i]) : 1.0f;
+    for (int a = 0; a < 4; ++a) {
+      const int il = wi * 128 + a * 32 + l31;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pt[il + (wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * TS] = acc[a][b][r];
+    }
+    return;
+  }
+  // Undo the row scales: the accumulator holds s_i s_j (X_a X_b^T)_ij; 1 / s is a power of two.
+  // A short contraction (the rank-256 updates of the Cholesky inverse) spends most of its time
+  // here, so the epilogue is laid out for memory latency: the 16 column scales of a block and
+  // the 16 old values of C (beta != 0) are loaded as independent batches from clamped addresses
+  // BEFORE the block's stores - interleaved with the stores through a pointer that may alias,
+  // every load waited for the store before it (~100 us per tile at K = 256).
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float uj[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      uj[r] = SplitScaleInv(ob.rowmax[j < N ? j : N - 1]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t i = i0 + wi * 128 + a * 32 + l31;
+      const int64_t ic = i < M ? i : M - 1;
+      const float ui = SplitScaleInv(oa.rowmax[ic]);
+      float old[16];
+      if (beta != 0.0f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          old[r] = C[ic + (j < N ? j : N - 1) * ldc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t j = j0 + wj * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (P != nullptr) {
-          P[(static_cast<int64_t>(blockIdx.x) * gridDim.y + blockIdx.y) * (TS * TS) + (i - i0) + (j - j0) * TS] =
-              acc[a][b][r];
-          continue;
-        }
         if (i >= M || j >= N) continue;
-        float* c = C + i + j * ldc;
-        const float v = alpha * ((ui * acc[a][b][r]) * (1.0f / SplitScale(ob.rowmax[j])));
-        *c = (beta == 0.0f) ? v : v + beta * (*c);
+        const float v = alpha * ((ui * acc[a][b][r]) * uj[r]);
+        C[i + j * ldc] = (beta == 0.0f) ? v : v + beta * old[r];
       }
     }
   }

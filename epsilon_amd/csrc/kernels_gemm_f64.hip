@@ -215,19 +215,31 @@ __global__ __launch_bounds__(kBlock, 2) void GemmMfmaF64PipeKernel(
   for (; kt < nk; ++kt) slab(std::false_type(), kt);
 
   // acc[a][b][reg]: i_local = l15 (the MFMA's column), j_local = lk + 4 * reg (its row)
+  // (beta != 0: the old values of a row of blocks are loaded as one batch before its stores -
+  // see the f32 kernel)
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int64_t i = li0 + wi * 64 + a * 16 + l15;
-    if (i < i0 || i >= M) continue;
+    const bool i_ok = i >= i0 && i < M;
+    const int64_t ic = i < M ? i : M - 1;
+    double old[4][4];
+    if (beta != 0.0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t j = lj0 + wj * 64 + b * 16 + lk + 4 * r;
+          old[b][r] = C[ic + (j < N ? j : N - 1) * ldc];
+        }
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t j = lj0 + wj * 64 + b * 16 + lk + 4 * r;
-        if (j < j0 || j >= N) continue;
-        double* c = C + i + j * ldc;
+        if (!i_ok || j < j0 || j >= N) continue;
         const double v = alpha * acc[a][b][r];
-        *c = (beta == 0.0) ? v : v + beta * (*c);
+        C[i + j * ldc] = (beta == 0.0) ? v : v + beta * old[b][r];
       }
     }
   }

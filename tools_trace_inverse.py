@@ -1,33 +1,34 @@
 #!/usr/bin/env python3
-"""Reads gpurun_out/prof_inv/inv_results.db (tools_trace_inverse.sh): the kernels of the LAST
-explicit inverse of the run in launch order, per phase (potrf | trtri | lauum): wall time, time
-per kernel name, and the GEMM launches by grid size."""
-import os
-ROOT = os.path.dirname(os.path.abspath(__file__))
+"""Per-kernel breakdown of ONE explicit inverse (first PotrfFusedStep launch .. last launch before
+the sweeps start) out of the rocprofv3 kernel trace of bench.py (gpurun_out/prof_stats)."""
 import re
 import sqlite3
+import sys
 
-con = sqlite3.connect(os.path.join(ROOT, 'gpurun_out', 'prof_inv', 'inv_results.db'))
-rows=list(con.execute("select name,start,end,grid_x,workgroup_x,grid_y,grid_z from kernels order by start"))
-def short(n):
-    n=re.sub(r"\(anonymous namespace\)::","",n); return re.sub(r"^void ","",n).split("(")[0].replace("eps::k::","")[:50]
-rows=[(short(r[0]),)+r[1:] for r in rows]
-sym=[i for i,r in enumerate(rows) if r[0].startswith("Symmetrize")]
-first_potrf=[i for i,r in enumerate(rows) if r[0].startswith("PotrfDiagStep")]
-lo=[i for i in first_potrf if i>sym[-2]][0] if len(sym)>1 else first_potrf[0]; hi=sym[-1]
-seg=rows[lo:hi+1]
-phase="potrf"; agg={}; wall={}
-for r in seg:
-    n,s,e,gx,wx,gy,gz=r
-    wgs=(gx//max(wx,1))*max(gy,1)*max(gz,1)
-    for k in ((phase,n,None),(phase,n,wgs)):
-        a=agg.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=(e-s)/1e3
-    w=wall.setdefault(phase,[s,e]); w[1]=e
-    if n.startswith("TrtriDiagBlocks"): phase="trtri"
-    elif phase=="trtri" and n.startswith("EwKernel"): phase="lauum"
-for ph in ("potrf","trtri","lauum"):
-    print("== %s wall %.2f ms"%(ph,(wall[ph][1]-wall[ph][0])/1e6))
-    for (p,n,g),(c,t) in sorted(agg.items(), key=lambda x:-x[1][1]):
-        if p==ph and g is None: print("   %-50s calls %4d total %8.1f us avg %7.1f"%(n,c,t,t/c))
-    for (p,n,g),(c,t) in sorted(agg.items(), key=lambda x:-x[1][1])[:60]:
-        if p==ph and g is not None and n.startswith("Gemm"): print("        wgs %5d %-40s calls %4d total %8.1f us avg %7.1f"%(g,n[:40],c,t,t/c))
+db = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_stats/stats_results.db"
+con = sqlite3.connect(db)
+rows = list(con.execute("select name, start, end, grid_x, grid_y, workgroup_x from kernels order by start"))
+names = [r[0] for r in rows]
+# the first FULL-SIZE inverse (the warm-up solve has a small one)
+idx = [i for i, n in enumerate(names) if "PotrfFusedStep" in n and rows[i][3] // max(1, rows[i][5]) > 100]
+start = idx[0]
+end = start
+while end < len(rows) and "LassoFused" not in names[end]:
+    end += 1
+t0 = rows[start][1]
+agg = {}
+prev_end, gaps = None, 0.0
+for r in rows[start:end]:
+    n = re.sub(r"\(anonymous namespace\)::", "", r[0]).split("(")[0][:50]
+    a = agg.setdefault(n, [0, 0.0])
+    a[0] += 1
+    a[1] += (r[2] - r[1]) / 1e3
+    if prev_end is not None:
+        gaps += max(0, r[1] - prev_end) / 1e3
+    prev_end = max(prev_end or 0, r[2])
+print("span %.2f ms, idle between kernels %.2f ms" % ((rows[end - 1][2] - t0) / 1e6, gaps / 1e3))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%-52s %4d %9.1f us" % (k, v[0], v[1]))
+for r in rows[start:end]:
+    if "GemmSplitF16Kernel" in r[0]:
+        print("split: workgroups %5d x %d  %7.1f us  at %.2f ms" % (r[3] // max(1, r[5]), r[4], (r[2] - r[1]) / 1e3, (r[1] - t0) / 1e6))
