@@ -403,7 +403,7 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
                   int64_t lda, const DVec& B, int64_t ldb, double beta, const DVec& C, int64_t ldc,
                   bool lower_only) {
   if (!SplitEnabled() || A.dt != F32 || B.dt != F32 || C.dt != F32) return false;
-  if (M < 2048 || N < 2048 || K < 256 || static_cast<double>(M) * N * K < 8.0e9) return false;
+  if (M < 1024 || N < 1024 || K < 256 || static_cast<double>(M) * N * K < 8.0e9) return false;
   if (lower_only && M != N) return false;
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();

@@ -30,5 +30,7 @@ print("span %.2f ms, idle between kernels %.2f ms" % ((rows[end - 1][2] - t0) / 
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print("%-52s %4d %9.1f us" % (k, v[0], v[1]))
 for r in rows[start:end]:
-    if "GemmSplitF16Kernel" in r[0]:
-        print("split: workgroups %5d x %d  %7.1f us  at %.2f ms" % (r[3] // max(1, r[5]), r[4], (r[2] - r[1]) / 1e3, (r[1] - t0) / 1e6))
+    if "GemmSplitF16Kernel" in r[0] or "GemmMfmaF32PipeKernel" in r[0]:
+        kind = "split" if "Split" in r[0] else "f32 " + r[0].split("<")[1].split(">")[0]
+        z = con.execute("select grid_z from kernels where start=?", (r[1],)).fetchone()[0]
+        print("%-16s workgroups %5d x %d x %d  %7.1f us  at %.2f ms" % (kind, r[3] // max(1, r[5]), r[4], z, (r[2] - r[1]) / 1e3, (r[1] - t0) / 1e6))
