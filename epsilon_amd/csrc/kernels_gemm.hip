@@ -481,7 +481,9 @@ __global__ __launch_bounds__(kBlock) void SyrkTailFixupKernel(int64_t M, int64_t
   while (I * (I + 1) / 2 > lin) --I;
   const int64_t i0 = I * MT, j0 = (lin - I * (I + 1) / 2) * MT;
   const float* p0 = P + static_cast<int64_t>(blockIdx.x) * S * (MT * MT);
-  for (int e = threadIdx.x; e < MT * MT; e += kBlock) {
+  const int per = MT * MT / static_cast<int>(gridDim.y);  // gridDim.y workgroups share a tile
+  const int e_begin = static_cast<int>(blockIdx.y) * per;
+  for (int e = e_begin + threadIdx.x; e < e_begin + per; e += kBlock) {
     const int64_t i = i0 + (e & (MT - 1)), j = j0 + (e >> 7);
     if (i >= M || j >= M) continue;
     float sum = p0[e];
@@ -741,7 +743,7 @@ void GemmBatched(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
         const int64_t first = static_cast<int64_t>(grid.x);
         dim3 tgrid(static_cast<unsigned>(tail), static_cast<unsigned>(S), 1);
         EPS_PIPE_ALL(tgrid, first, kchunk, P);
-        hipLaunchKernelGGL(SyrkTailFixupKernel, dim3(static_cast<unsigned>(tail)), dim3(kBlock), 0, s, M,
+        hipLaunchKernelGGL(SyrkTailFixupKernel, dim3(static_cast<unsigned>(tail), 8), dim3(kBlock), 0, s, M,
                            first, S, P, al, be, C.as<float>(), ldc);
       }
 #undef EPS_PIPE_ALL
