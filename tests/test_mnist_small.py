@@ -56,7 +56,11 @@ def test_multiclass_hinge_on_mnist_small_matches_oracle(solve_mod, solver_id, dt
     g, o = wire.SolverStatus.FromString(st_g), wire.SolverStatus.FromString(st_o)
     assert o.state == wire.SolverStatus.OPTIMAL
     assert g.state == o.state and g.num_iterations == o.num_iterations, (g, o)
-    rt = 1e-7 if dt == "f64" else 2e-3
+    # fp32 + two-block driver: the block factorisation's Schur complement has condition number
+    # ~1e5 here (see below), so the residual norms themselves move by cond * eps ~ 1e-2 with the
+    # rounding order of the triangular solves (0.2 % with the blocked forward substitution of the
+    # Cholesky steps, 0.4 % with the one that rides on the factorisation's broadcasts)
+    rt = 1e-7 if dt == "f64" else (1e-2 if solver_id == 1 else 2e-3)
     for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
         np.testing.assert_allclose(getattr(g.residuals, f), getattr(o.residuals, f), rtol=rt, atol=1e-6)
     # iterates: fp64 to rounding; fp32 within 1e-2 of the largest entry of each variable (the
