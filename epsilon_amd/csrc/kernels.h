@@ -117,6 +117,9 @@ bool GemmF64Pipe(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                  int64_t lda, int64_t sA, const DVec& B, int64_t ldb, int64_t sB, double beta,
                  const DVec& C, int64_t ldc, int64_t sC, int64_t n1, int64_t batch, bool lower_only,
                  int64_t sA2, int64_t sB2);
+// Lower tiles of C = X^T X for a lower-triangular X (zeros stored above the diagonal) in one launch
+// of the split-f16 kernel with a k range per tile; false: not eligible (f32, n >= 2048), nothing done.
+bool SyrkSplitF16LowerTriangular(int64_t n, const DVec& X, int64_t ldx, const DVec& C, int64_t ldc);
 // C (M x N, ldc == M, N <= 16) = alpha op(A) B + beta C as a mat-vec with N right-hand sides
 // (kernels_gemv_multi.hip); false if the shape / alignment is not covered (nothing is done).
 bool MultiGemv(bool transA, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,

@@ -507,7 +507,7 @@ void SpdInverseInPlace(const DVec& W, int64_t n) {
   // ---- 3. W^-1 = X^T X ------------------------------------------------------------------------
   // Row block p of the lower-triangular X is zero right of column (p+1)*B, so it only touches
   // the leading (p+1)B x (p+1)B corner of X^T X: a third of the flops of the dense product.
-  {
+  if (!SyrkSplitF16LowerTriangular(n, X, ld, W, ld)) {
     const int64_t B = 1024;
     Fill(W.Slice(0, n * n), 0.0);
     for (int64_t p0 = 0; p0 < n; p0 += B) {

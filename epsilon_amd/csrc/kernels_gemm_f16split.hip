@@ -195,6 +195,9 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
   const int64_t i0 = I * TS, j0 = J * TS;
   // split-K form (tail tiles): blockIdx.y selects a run of slabs
   int64_t ks0 = slab0, ks1 = slab0 + slab_count;
+  // tri == 2: X^T X of a LOWER-TRIANGULAR X (rows of the operands = columns of X, k = its rows):
+  // column i of X is zero above row i, so tile (I, J), I >= J, only has terms from k >= i0 on
+  if (tri == 2 && i0 / SK > ks0) ks0 = i0 / SK;
   if (P != nullptr) {
     ks0 = slab0 + static_cast<int64_t>(blockIdx.y) * slab_count;
     ks1 = ks0 + slab_count;
@@ -458,6 +461,25 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
     hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail), 16), dim3(256), 0, s, M, full, S,
                        P, oa.rowmax, al, be, C.as<float>(), ldc);
   }
+  EPS_HIP(hipGetLastError());
+  return true;
+}
+
+// C (lower tiles, n x n) = X^T X for a lower-triangular X (n x n, column-major, zeros above the
+// diagonal stored): the last product of the explicit inverse, W^-1 = L^-T L^-1.  ONE launch over
+// the lower tiles, each with its own k range (tri == 2 above) - a third of the dense flops, no
+// accumulation passes over C.  Tiles are dispatched in order of decreasing k length.
+bool SyrkSplitF16LowerTriangular(int64_t n, const DVec& X, int64_t ldx, const DVec& C, int64_t ldc) {
+  if (!SplitEnabled() || X.dt != F32 || C.dt != F32 || n < 2048) return false;
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  ProfScope prof("syrk_f16split_tri", n * n, n);
+  const int64_t nslab = (n + SK - 1) / SK;
+  ConvertedOperand cx = ConvertOperand(X.as<float>(), n, n, ldx, false);  // rows = columns of X
+  const int64_t T = (n + TS - 1) / TS;
+  hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(T * (T + 1) / 2)), dim3(kThreads), 0, s, n, n,
+                     nslab, cx.op, cx.op, 1.0f, 0.0f, C.as<float>(), ldc, 2, static_cast<int64_t>(0),
+                     static_cast<int64_t>(0), nslab, static_cast<float*>(nullptr));
   EPS_HIP(hipGetLastError());
   return true;
 }
