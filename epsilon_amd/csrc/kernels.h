@@ -117,6 +117,10 @@ bool GemmF64Pipe(bool transA, bool transB, int64_t M, int64_t N, int64_t K, doub
                  int64_t lda, int64_t sA, const DVec& B, int64_t ldb, int64_t sB, double beta,
                  const DVec& C, int64_t ldc, int64_t sC, int64_t n1, int64_t batch, bool lower_only,
                  int64_t sA2, int64_t sB2);
+// C = alpha A B (no transposes, beta = 0) with B (kmode 3) or A (kmode 4) lower triangular, on the
+// split-f16 kernel with a k range per tile; false: not eligible, nothing done.
+bool GemmSplitF16KRange(int kmode, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,
+                        const DVec& B, int64_t ldb, const DVec& C, int64_t ldc);
 // Lower tiles of C = X^T X for a lower-triangular X (zeros stored above the diagonal) in one launch
 // of the split-f16 kernel with a k range per tile; false: not eligible (f32, n >= 2048), nothing done.
 bool SyrkSplitF16LowerTriangular(int64_t n, const DVec& X, int64_t ldx, const DVec& C, int64_t ldc);

@@ -579,13 +579,16 @@ void DoublingInverse(const DVec& W, const DVec& X, int64_t n, const DVec& dinv, 
       const int64_t tiles = ((s1 + 127) / 128) * ((s2 + 127) / 128);
       const int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>(4, tiles / 400));
       const int64_t cb = (s1 + nsplit - 1) / nsplit;
-      for (int64_t c0 = 0; c0 < s1; c0 += cb) {
+      // (large f32 levels: one launch each with a k range per tile, kernels_gemm_f16split.hip)
+      const bool t_done = GemmSplitF16KRange(3, s2, s1, s1, 1.0, L21, ld, X11, ld, T, s2);
+      for (int64_t c0 = 0; c0 < s1 && !t_done; c0 += cb) {
         const int64_t cw = std::min<int64_t>(cb, s1 - c0);
         Gemm(false, false, s2, cw, s1 - c0, 1.0, Sub(L21, 0, c0, ld), ld, Sub(X11, c0, c0, ld), ld,
              0.0, T.Slice(c0 * s2, cw * s2), s2);
       }
       const int64_t rb = (s2 + nsplit - 1) / nsplit;
-      for (int64_t r1 = 0; r1 < s2; r1 += rb) {
+      const bool x_done = GemmSplitF16KRange(4, s2, s1, s2, -1.0, X22, ld, T, s2, X21, ld);
+      for (int64_t r1 = 0; r1 < s2 && !x_done; r1 += rb) {
         const int64_t rw = std::min<int64_t>(rb, s2 - r1);
         Gemm(false, false, rw, s1, r1 + rw, -1.0, Sub(X22, r1, 0, ld), ld, T, s2, 0.0,
              Sub(X21, r1, 0, ld), ld);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
   __shared__ __attribute__((aligned(16))) _Float16 sm[4][TS * LROW];  // H_I, L_I, H_J, L_J: 80 KB
   const int64_t lin = lin0 + blockIdx.x;
   int64_t I, J;
-  if (tri) {  // tile (I, J), I >= J, from the linear index over the lower triangle
+  if (tri == 1 || tri == 2) {  // tile (I, J), I >= J, from the linear index over the lower triangle
     I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= lin) ++I;
     while (I * (I + 1) / 2 > lin) --I;
@@ -198,6 +198,11 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
   // tri == 2: X^T X of a LOWER-TRIANGULAR X (rows of the operands = columns of X, k = its rows):
   // column i of X is zero above row i, so tile (I, J), I >= J, only has terms from k >= i0 on
   if (tri == 2 && i0 / SK > ks0) ks0 = i0 / SK;
+  // full grid, one operand lower triangular (the doubling levels of the triangular inverse):
+  // tri == 3: B(k, j) = 0 for k < j - terms from k >= j0 on; tri == 4: A(i, k) = 0 for k > i -
+  // terms up to the tile's last row
+  if (tri == 3 && j0 / SK > ks0) ks0 = j0 / SK;
+  if (tri == 4 && (i0 + TS + SK - 1) / SK < ks1) ks1 = (i0 + TS + SK - 1) / SK;
   if (P != nullptr) {
     ks0 = slab0 + static_cast<int64_t>(blockIdx.y) * slab_count;
     ks1 = ks0 + slab_count;
@@ -461,6 +466,29 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
     hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail), 16), dim3(256), 0, s, M, full, S,
                        P, oa.rowmax, al, be, C.as<float>(), ldc);
   }
+  EPS_HIP(hipGetLastError());
+  return true;
+}
+
+// C (M x N) = alpha A B with ONE operand lower triangular (zeros stored): kmode 3: B (K x N, its
+// rows k and columns j on the same index: B(k, j) = 0 for k < j); kmode 4: A (M x K, A(i, k) = 0
+// for k > i).  Every tile runs over its own k range - half the flops of the dense product in one
+// launch.  false: not eligible, nothing done.
+bool GemmSplitF16KRange(int kmode, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,
+                        const DVec& B, int64_t ldb, const DVec& C, int64_t ldc) {
+  if (!SplitEnabled() || A.dt != F32 || B.dt != F32 || C.dt != F32) return false;
+  if (M < 1024 || N < 1024 || K < 256 || static_cast<double>(M) * N * K < 8.0e9) return false;
+  if (kmode != 3 && kmode != 4) return false;
+  Runtime& rt = Runtime::Get();
+  hipStream_t s = rt.stream();
+  ProfScope prof("gemm_f16split_krange", M * N, K);
+  const int64_t nslab = (K + SK - 1) / SK;
+  ConvertedOperand ca = ConvertOperand(A.as<float>(), M, K, lda, true);   // A(i, k) = A[i + k lda]
+  ConvertedOperand cb = ConvertOperand(B.as<float>(), N, K, ldb, false);  // B(k, j) = B[k + j ldb]
+  const int64_t TI = (M + TS - 1) / TS, TJ = (N + TS - 1) / TS;
+  hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(TI * TJ)), dim3(kThreads), 0, s, M, N, nslab,
+                     ca.op, cb.op, static_cast<float>(alpha), 0.0f, C.as<float>(), ldc, kmode,
+                     static_cast<int64_t>(0), static_cast<int64_t>(0), nslab, static_cast<float*>(nullptr));
   EPS_HIP(hipGetLastError());
   return true;
 }
