@@ -30,6 +30,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -399,6 +400,13 @@ ConvertedOperand ConvertOperand(const float* X, int64_t rows, int64_t K, int64_t
   return c;
 }
 
+// EPSILON_HIP_GEMM = generic / mfma / mfma_simple forces another kernel family (read on every
+// call: the tests switch it between products)
+bool AutoKernelChoice() {
+  const char* e = std::getenv("EPSILON_HIP_GEMM");
+  return e == nullptr || e[0] == 0 || std::strcmp(e, "auto") == 0;
+}
+
 bool SplitEnabled() {
   static const bool off = [] {
     const char* e = std::getenv("EPSILON_HIP_GRAM_F16SPLIT");
@@ -476,7 +484,7 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
 // launch.  false: not eligible, nothing done.
 bool GemmSplitF16KRange(int kmode, int64_t M, int64_t N, int64_t K, double alpha, const DVec& A, int64_t lda,
                         const DVec& B, int64_t ldb, const DVec& C, int64_t ldc) {
-  if (!SplitEnabled() || A.dt != F32 || B.dt != F32 || C.dt != F32) return false;
+  if (!SplitEnabled() || !AutoKernelChoice() || A.dt != F32 || B.dt != F32 || C.dt != F32) return false;
   if (M < 1024 || N < 1024 || K < 256 || static_cast<double>(M) * N * K < 8.0e9) return false;
   if (kmode != 3 && kmode != 4) return false;
   Runtime& rt = Runtime::Get();
@@ -498,7 +506,7 @@ bool GemmSplitF16KRange(int kmode, int64_t M, int64_t N, int64_t K, double alpha
 // the lower tiles, each with its own k range (tri == 2 above) - a third of the dense flops, no
 // accumulation passes over C.  Tiles are dispatched in order of decreasing k length.
 bool SyrkSplitF16LowerTriangular(int64_t n, const DVec& X, int64_t ldx, const DVec& C, int64_t ldc) {
-  if (!SplitEnabled() || X.dt != F32 || C.dt != F32 || n < 2048) return false;
+  if (!SplitEnabled() || !AutoKernelChoice() || X.dt != F32 || C.dt != F32 || n < 2048) return false;
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
   ProfScope prof("syrk_f16split_tri", n * n, n);
