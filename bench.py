@@ -9,8 +9,10 @@ src/epsilon/algorithms/prox_admm.cc:134-159) including the residual check the re
 every `epoch_iterations` sweeps.  Inputs are synthetic (reference recipe
 python/epopt/problems/lasso.py:8-15 + problem_util.py:9-42, x0 density 0.01 as
 problems/benchmark.py:37), generated on the device and resident in HBM before any timing.
-For N > 1 the same problem is column-sharded over the ranks (strong scaling) with one RCCL
-all-reduce of m floats per sweep.  Rank 0 prints ONE JSON line.
+For N > 1 the same problem is column-sharded over the ranks (strong scaling), one m-float exchange
+per sweep.  Launched as one rank per GPU by torch.distributed.run - or, when called without a
+rank environment, by bench.py itself, which then starts that command as a child process.  Rank 0
+prints ONE JSON line.
 """
 
 import argparse
@@ -125,10 +127,19 @@ def cpu_info():
 
 
 def cpu_baseline(At, b, lam, iters_to_eps=None, budget_s=10.0):
-    """The oracle's plain-C restatement of the same sweep (oracle/lasso_sweep.c), fp64, timed on
-    the host cores of this box on a bounded number of full-size sweeps: at ONE thread (the
-    reference is single-threaded by design: tools/run_benchmarks.sh:15-17) and at all usable
-    cores (OpenMP over the three mat-vecs).  Returns (one-thread object, all-cores object)."""
+    """The reference's CPU path timed on this box's host cores, on a bounded sample of the same
+    workload.  Returns (cpu_baseline, cpu_baseline_all_cores):
+
+    * cpu_baseline, kind "reference": the unrolled lasso sweep with its three mat-vecs through the
+      dgemv_ of the reference's OWN tree (third_party/eigen/blas, compiled from there into
+      oracle/_ref/libref.so by oracle/Makefile; oracle/ref_driver.cc: ref_lasso_sweeps), fp64, ONE
+      thread - the reference is single-threaded by design (tools/run_benchmarks.sh:15-17).  Init
+      (Gram + explicit inverse) through the same tree's dgemm_ and Eigen::LDLT
+      (linear_map_multiply.cc:14-37, dense_matrix_impl.cc:21-30) at 1/4 scale, extrapolated by the
+      m^2 n / m^3 laws - an estimate, stated as such.
+    * cpu_baseline_all_cores, kind "port": the plain-C restatement (oracle/lasso_sweep.c) with
+      OpenMP over the mat-vecs on all usable cores - what the box could do, not what the reference does.
+    Falls back to the port at one thread (kind "port") where oracle/_ref was never built."""
     from oracle import c_oracle
     n, m = At.shape
     A = np.asfortranarray(At.t().double().cpu().numpy())  # m x n column-major fp64
@@ -142,84 +153,107 @@ def cpu_baseline(At, b, lam, iters_to_eps=None, budget_s=10.0):
     model, logical, usable = cpu_info()
     # all cores the process may use; capped at 64 (the mat-vecs are memory-bound long before)
     threads_all = max(1, min(usable, c_oracle.max_threads(), 64))
-
-    def time_sweeps(threads):
-        c_oracle.set_threads(threads)
-        st = c_oracle.LassoState(n)
-        t0 = time.time()
-        c_oracle.lasso_run(A, Minv, bb, lam, st, 1, abs_tol=0, rel_tol=0)
-        t1 = time.time() - t0
-        k = int(max(2, min(40, budget_s / max(t1, 1e-3))))
-        t0 = time.time()
-        done = c_oracle.lasso_run(A, Minv, bb, lam, st, k, abs_tol=0, rel_tol=0)
-        return done, time.time() - t0
-
-    # Init of the CPU path (Gram + explicit inverse, 2 m^2 n + ~2.3 m^3 flop) on a 1/8-scale
-    # instance, extrapolated by the m^2 n / m^3 law (x 512) - an ESTIMATE, stated as such
-    ms, ns = max(64, m // 8), max(64, n // 8)
-    As = np.asfortranarray(A[:ms, :ns])
-    init_est = {}
-    for threads in sorted({1, threads_all}):
-        c_oracle.set_threads(threads)
-        t0 = time.time()
-        G = c_oracle.gram(As)
-        t_gram = time.time() - t0
-        t0 = time.time()
-        if threads == 1:
-            import scipy.linalg
-            c, low = scipy.linalg.cho_factor(np.eye(ms) + 2 * G)
-            scipy.linalg.cho_solve((c, low), np.eye(ms))
-            t_inv = time.time() - t0
-            init_est["inverse_sample_s"] = t_inv
-        scale = (float(m) / ms) ** 2 * (float(n) / ns)
-        init_est[threads] = t_gram * scale + init_est["inverse_sample_s"] * (float(m) / ms) ** 3
-    out = []
-    for threads in sorted({1, threads_all}):
-        done, dt = time_sweeps(threads)
-        o = {
-            "value": done / dt, "unit": "iter/s", "cores": threads, "kind": "port",
-            "sample": "%d full-size sweeps (m=%d n=%d fp64, A = the GPU instance, synthetic m x m "
-                      "operator) of oracle/lasso_sweep.c, gcc -O3 -fopenmp, %d thread%s"
-                      % (done, m, n, threads, "" if threads == 1 else "s"),
-            "ms_per_step": 1e3 * dt / done,
-            "cpu_model": model, "host_logical_cpus": logical, "host_usable_cpus": usable,
-            "init_s_estimate": init_est[threads],
-            "init_estimate_note": "Gram (plain-C blocked A A^T, %d thread%s) + Cholesky inverse (LAPACK via "
-                                  "scipy; its threading is the library's) timed at %d x %d and scaled by "
-                                  "m^2 n resp. m^3 to %d x %d" % (threads, "" if threads == 1 else "s",
-                                                                  ms, ns, m, n),
-        }
-        if iters_to_eps:
-            o["time_to_eps_s_estimate"] = init_est[threads] + iters_to_eps * dt / done
-            o["time_to_eps_note"] = "Init estimate + %d sweeps (the GPU run's count to OPTIMAL) at the measured CPU rate" % iters_to_eps
-        out.append(o)
-    c_oracle.set_threads(1)
-    # cross-check of the port's mat-vecs against the BLAS in the reference's own tree (vendored
-    # Eigen, built into oracle/_ref by oracle/Makefile where the reference exists): one A x and one
-    # A^T w through its dgemv_, single thread
+    ref = None
     try:
         from oracle import ref_lib
         if ref_lib.available():
-            xx, ww = rng.randn(n), rng.randn(m)
-            ref_lib.dgemv(A[:, :8], xx[:8])  # load the library
-            t0 = time.time()
-            ref_lib.dgemv(A, xx)
-            t_n = time.time() - t0
-            t0 = time.time()
-            ref_lib.dgemv(A, ww, trans=True)
-            t_t = time.time() - t0
-            out[0]["reference_tree_blas"] = {
-                "library": "oracle/_ref/libref.so (third_party/eigen/blas of the reference, g++ -O3 -DNDEBUG)",
-                "dgemv_N_ms": 1e3 * t_n, "dgemv_T_ms": 1e3 * t_t,
-                "note": "the port's sweep is 2 such mat-vecs + the m x m apply: %.0f ms with this BLAS' mat-vecs "
-                        "against %.0f ms measured for the port's whole sweep" % (1e3 * (t_n + t_t), out[0]["ms_per_step"])}
-    except Exception as e:  # the cross-check is optional
-        out[0]["reference_tree_blas"] = {"error": str(e)}
-    return out[0], out[-1]
+            ref_lib.dgemv(A[:, :8], np.zeros(8))  # load the library
+            ref = ref_lib
+    except Exception:
+        ref = None
+
+    def time_sweeps(run, budget):
+        st = c_oracle.LassoState(n)
+        t0 = time.time()
+        run(st, 1)
+        t1 = time.time() - t0
+        k = int(max(2, min(40, budget / max(t1, 1e-3))))
+        t0 = time.time()
+        run(st, k)
+        return k, time.time() - t0
+
+    def port_run(threads):
+        def run(st, k):
+            c_oracle.set_threads(threads)
+            c_oracle.lasso_run(A, Minv, bb, lam, st, k, abs_tol=0, rel_tol=0)
+        return run
+
+    def entry(done, dt, threads, kind, sample, init_s, init_note):
+        o = {"value": done / dt, "unit": "iter/s", "cores": threads, "kind": kind, "sample": sample,
+             "ms_per_step": 1e3 * dt / done, "cpu_model": model, "host_logical_cpus": logical,
+             "host_usable_cpus": usable, "init_s_estimate": init_s, "init_estimate_note": init_note}
+        if iters_to_eps:
+            o["time_to_eps_s_estimate"] = init_s + iters_to_eps * dt / done
+            o["time_to_eps_note"] = ("Init estimate + %d sweeps (the GPU run's count to OPTIMAL) at the "
+                                     "measured CPU rate" % iters_to_eps)
+        return o
+
+    # ---- one thread: the reference tree's own BLAS / LDLT where built
+    if ref is not None:
+        done, dt = time_sweeps(lambda st, k: ref.lasso_sweeps(A, Minv, bb, lam, st, k), budget_s)
+        # Init on a 1/4-scale instance (2500 x 12500 at the default size): ~1.6e11 flop of dgemm_ +
+        # the LDLT inverse, ~10-20 s on one thread
+        ms, ns = max(64, m // 4), max(64, n // 4)
+        As = np.asfortranarray(A[:ms, :ns])
+        t0 = time.time()
+        G = ref.dgemm(As, As, tb=True)
+        t_gram = time.time() - t0
+        t0 = time.time()
+        ref.ldlt_inverse(np.eye(ms) + 2 * G)
+        t_inv = time.time() - t0
+        inv_full_s = t_inv * (float(m) / ms) ** 3
+        init_s = t_gram * (float(m) / ms) ** 2 * (float(n) / ns) + inv_full_s
+        one = entry(done, dt, 1, "reference",
+                    "%d full-size sweeps (m=%d n=%d fp64, A = the GPU instance, synthetic m x m operator): "
+                    "the unrolled sweep of prox_admm.cc:131-169 with all three mat-vecs through dgemv_ of the "
+                    "reference's own tree (oracle/_ref/libref.so = third_party/eigen/blas, g++ -O3 -DNDEBUG), 1 thread"
+                    % (done, m, n), init_s,
+                    "Gram through the same tree's dgemm_ (%.2f s) + Eigen::LDLT solve(I) (%.2f s) timed at %d x %d "
+                    "and scaled by m^2 n resp. m^3 to %d x %d" % (t_gram, t_inv, ms, ns, m, n))
+    else:
+        done, dt = time_sweeps(port_run(1), budget_s)
+        ms, ns = max(64, m // 8), max(64, n // 8)
+        As = np.asfortranarray(A[:ms, :ns])
+        c_oracle.set_threads(1)
+        t0 = time.time()
+        G = c_oracle.gram(As)
+        t_gram = time.time() - t0
+        import scipy.linalg
+        t0 = time.time()
+        c, low = scipy.linalg.cho_factor(np.eye(ms) + 2 * G)
+        scipy.linalg.cho_solve((c, low), np.eye(ms))
+        t_inv = time.time() - t0
+        inv_full_s = t_inv * (float(m) / ms) ** 3
+        init_s = t_gram * (float(m) / ms) ** 2 * (float(n) / ns) + inv_full_s
+        one = entry(done, dt, 1, "port",
+                    "%d full-size sweeps (m=%d n=%d fp64) of oracle/lasso_sweep.c, gcc -O3, 1 thread "
+                    "(oracle/_ref not built on this box)" % (done, m, n), init_s,
+                    "plain-C Gram + LAPACK Cholesky inverse (scipy) at %d x %d, scaled" % (ms, ns))
+    # ---- all usable cores: the OpenMP port (what the box could do; not the reference's configuration)
+    done_a, dt_a = time_sweeps(port_run(threads_all), budget_s / 2)
+    ms, ns = max(64, m // 8), max(64, n // 8)
+    As = np.asfortranarray(A[:ms, :ns])
+    c_oracle.set_threads(threads_all)
+    t0 = time.time()
+    c_oracle.gram(As)
+    t_gram_a = time.time() - t0
+    c_oracle.set_threads(1)
+    # the inverse is not threaded in the port: the one-thread figure of the first leg, scaled
+    allc = entry(done_a, dt_a, threads_all, "port",
+                 "%d full-size sweeps (m=%d n=%d fp64) of oracle/lasso_sweep.c, gcc -O3 -fopenmp, %d threads"
+                 % (done_a, m, n, threads_all),
+                 t_gram_a * (float(m) / ms) ** 2 * (float(n) / ns) + inv_full_s,
+                 "plain-C blocked Gram on %d threads at %d x %d scaled by m^2 n + the one-thread inverse of the first leg"
+                 % (threads_all, ms, ns))
+    return one, allc
 
 
 def main():
     args = parse()
+    # `python bench.py --gpus N` without a rank environment: start the N ranks as a child
+    # torch.distributed.run (decided before torch / HIP are touched; exits with the child's code)
+    from epsilon_amd import launch
+    launch.self_launch_if_needed(__file__, args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -242,7 +276,9 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     elif world > 1:
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch %d ranks, or none and let bench.py "
+                 "start them)" % (args.gpus, world, args.gpus))
 
     m, n = args.m, args.n
     _solve.set_option("dtype", args.dtype)

@@ -25,10 +25,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--m", type=int, default=10000)
-    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--m", "--rows", dest="m", type=int, default=10000)
+    ap.add_argument("--n", "--cols", dest="n", type=int, default=50000)
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     args = ap.parse_args()
+    # no rank environment: start the ranks as a child torch.distributed.run (before torch / HIP)
+    from epsilon_amd import launch
+    launch.self_launch_if_needed(__file__, args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

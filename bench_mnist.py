@@ -23,12 +23,15 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--m", type=int, default=60000)
+    ap.add_argument("--m", "--rows", dest="m", type=int, default=60000)
     ap.add_argument("--features", type=int, default=784)
     ap.add_argument("--classes", type=int, default=10)
     ap.add_argument("--lam", type=float, default=1.0)
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     a = ap.parse_args()
+    # no rank environment: start the ranks as a child torch.distributed.run (before torch / HIP)
+    from epsilon_amd import launch
+    launch.self_launch_if_needed(__file__, a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

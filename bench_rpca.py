@@ -24,7 +24,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--size", "--n", dest="n", type=int, default=10000,
+    ap.add_argument("--size", "--n", "--cols", dest="n", type=int, default=10000,
                     help="matrix size (use --size under torchrun: its parser claims the prefix --n)")
     ap.add_argument("--rank", type=int, default=10)
     ap.add_argument("--max-iterations", type=int, default=300)
@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--comm", default="rccl", choices=["rccl", "host"])
     a = ap.parse_args()
+    # no rank environment: start the ranks as a child torch.distributed.run (before torch / HIP)
+    from epsilon_amd import launch
+    launch.self_launch_if_needed(__file__, a.gpus)
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -277,6 +277,13 @@ def shard_consensus_terms(on=True):
     _check(lib().eps_shard_consensus_terms(ctypes.c_int(1 if on else 0)))
 
 
+def block_solve_stats(reset=False):
+    """(largest kappa_1 estimate of a pivot block, refinement steps) since the last reset (fp32)."""
+    c, r = ctypes.c_double(0), ctypes.c_int(0)
+    _check(lib().eps_block_solve_stats(ctypes.byref(c), ctypes.byref(r), ctypes.c_int(1 if reset else 0)))
+    return c.value, r.value
+
+
 def profile_enable(on=True):
     _check(lib().eps_profile_enable(ctypes.c_int(1 if on else 0)))
 

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <sstream>
 #include <unordered_set>
@@ -534,12 +535,39 @@ void RegisterGlobalDims(const BlockMatrix& A) {
 }
 }  // namespace
 
+BlockSolveStats& BlockSolveStats::Get() {
+  static BlockSolveStats s;
+  return s;
+}
+
+namespace {
+// Number of refinement steps for a block solve whose worst pivot block has kappa_1 = cond, in
+// fp32.  The explicit-inverse elimination is the normal-equations route: its forward error is
+// ~ cond * 6e-8 per solve although the KKT system itself is far better conditioned (a
+// projection has norm 1).  One step of refinement against the ORIGINAL blocks multiplies the
+// error by ~ cond * 6e-8 again, down to cond(KKT) * 6e-8.  EPSILON_HIP_REFINE = <steps> forces a
+// count (0 = the unrefined reference sequence of operations), "auto" / unset = by estimate.
+int RefineStepsFor(double cond) {
+  if (const char* e = std::getenv("EPSILON_HIP_REFINE")) {
+    if (e[0] >= '0' && e[0] <= '9') return std::atoi(e);
+  }
+  if (!(cond > 1e3)) return 0;  // unrefined error <= ~1e-4, the fp32 mode's stated tolerance
+  if (cond <= 3e4) return 1;
+  if (cond <= 3e6) return 2;
+  return 3;
+}
+}  // namespace
+
 // Block LDL^T by successive elimination, A = L D L^T with unit block lower triangular L stored
 // as L - I (reference block_cholesky.cc:119-133): pick the pivot key, invert its diagonal
 // block, record the scaled column, subtract the Schur update from what is left.
 void BlockCholesky::Compute(BlockMatrix A) {
   RegisterGlobalDims(A);
   const ShardSpec& sh = ShardSpec::Get();
+  A_ = A;
+  cond_ = 1.0;
+  refine_steps_ = 0;
+  bool any_f32 = false;
   for (size_t left = A.col_keys().size(); left > 0; --left) {
     const std::string pivot = NextKey(A);
     const LinearMap& block = A(pivot, pivot);
@@ -551,6 +579,11 @@ void BlockCholesky::Compute(BlockMatrix A) {
     Dinv(pivot, pivot) =
         split_over_ranks ? LinearMap(static_cast<const DenseMatrixImpl&>(block.impl()).InverseDistributed())
                          : block.Inverse();
+    if (MapDType(block.impl(), CurrentDType()) == F32) {
+      any_f32 = true;
+      const double c = ConditionEstimate(block, Dinv(pivot, pivot));
+      if (c > cond_ && std::isfinite(c)) cond_ = c;
+    }
     const BlockMatrix V = DetachKey(&A, pivot);
     const BlockMatrix column = V * Dinv;
     A = A - column * V.Transpose();
@@ -559,10 +592,30 @@ void BlockCholesky::Compute(BlockMatrix A) {
     p_.push_back(pivot);
   }
   LT_ = L_.Transpose();
+  if (any_f32) {
+    // sharded blocks differ between ranks, the step count must not (the residual's products
+    // contain collectives)
+    if (sh.active()) cond_ = Runtime::Get().comm()->AllReduceMaxHost(cond_);
+    refine_steps_ = RefineStepsFor(cond_);
+  }
+  if (refine_steps_ == 0) A_ = BlockMatrix();
+  BlockSolveStats& st = BlockSolveStats::Get();
+  st.max_condition = std::max(st.max_condition, cond_);
+  st.max_refine_steps = std::max(st.max_refine_steps, refine_steps_);
 }
 
-BlockVector BlockCholesky::Solve(const BlockVector& b) const {  // :135-137
+BlockVector BlockCholesky::SolveOnce(const BlockVector& b) const {  // :135-137
   return BackSub(LT_, p_, D_inv_ * ForwardSub(L_, p_, b));
+}
+
+BlockVector BlockCholesky::Solve(const BlockVector& b) const {
+  BlockVector x = SolveOnce(b);
+  // fp32 with ill-conditioned pivot blocks only: x += solve(b - A x) against the blocks as given
+  for (int s = 0; s < refine_steps_; ++s) {
+    BlockVector r = b - A_ * x;
+    x += SolveOnce(r);
+  }
+  return x;
 }
 
 }  // namespace eps

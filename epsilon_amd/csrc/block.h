@@ -113,10 +113,29 @@ class BlockCholesky {
   const std::vector<std::string>& order() const { return p_; }
   const BlockMatrix& L() const { return L_; }
   const BlockMatrix& D_inv() const { return D_inv_; }
+  // fp32 mode only (no reference counterpart - the reference factors in fp64): the largest
+  // kappa_1 over the pivot blocks, and the number of iterative-refinement steps Solve() adds
+  // because of it (0 for well-conditioned systems: Solve is then exactly the reference's
+  // back-sub(D^-1 forward-sub)).  See Compute().
+  double condition_estimate() const { return cond_; }
+  int refine_steps() const { return refine_steps_; }
 
  private:
+  BlockVector SolveOnce(const BlockVector& b) const;
   std::vector<std::string> p_;
   BlockMatrix D_inv_, L_, LT_;
+  BlockMatrix A_;  // the matrix as given (shares every block's buffer): refinement residuals
+  double cond_ = 1.0;
+  int refine_steps_ = 0;
+};
+
+// Process-wide record of the last factorisations' condition estimates (tests / diagnostics):
+// the largest estimate and refinement step count since the last reset.
+struct BlockSolveStats {
+  double max_condition = 0;
+  int max_refine_steps = 0;
+  static BlockSolveStats& Get();
+  void Reset() { max_condition = 0; max_refine_steps = 0; }
 };
 
 }  // namespace eps

@@ -130,6 +130,9 @@ int eps_set_option(const char* key, const char* value) {
       Runtime::Get().set_prof_filter(value);
     } else if (std::strcmp(key, "fused") == 0) {
       setenv("EPSILON_HIP_FUSED", value, 1);
+    } else if (std::strcmp(key, "refine") == 0) {
+      if (std::strcmp(value, "auto") == 0) unsetenv("EPSILON_HIP_REFINE");
+      else setenv("EPSILON_HIP_REFINE", value, 1);
     } else {
       EPS_FATAL("unknown option " << key);
     }
@@ -382,6 +385,15 @@ int eps_shard_keys(const char* const* keys, size_t nkeys) {
 
 int eps_shard_consensus_terms(int on) {
   return Guard([&] { ShardSpec::Get().set_consensus_terms(on != 0); });
+}
+
+int eps_block_solve_stats(double* max_condition, int* max_refine_steps, int reset) {
+  return Guard([&] {
+    BlockSolveStats& st = BlockSolveStats::Get();
+    if (max_condition) *max_condition = st.max_condition;
+    if (max_refine_steps) *max_refine_steps = st.max_refine_steps;
+    if (reset) st.Reset();
+  });
 }
 
 int eps_profile_enable(int on) {

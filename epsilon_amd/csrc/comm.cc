@@ -4,8 +4,10 @@
 
 #include <cstdlib>
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <memory>
+#include <sstream>
 #include <vector>
 
 #include "kernels.h"
@@ -180,17 +182,45 @@ namespace {
 
 // Window memory must be readable mid-kernel by a GPU other than the one that wrote it: take
 // uncached / fine-grained device memory when the runtime offers it (what RCCL does for its own
-// peer buffers), plain device memory otherwise (all accesses to it are system-scope anyway).
-void* AllocWindow(size_t bytes) {
+// peer buffers).  Plain hipMalloc memory is the last resort and only good between ranks that share
+// ONE device (the one-GPU rehearsals and tests): polled from another device, a plain coarse-grained
+// line is exactly the stale-line case of MI355X_MICROARCH.md ("Inter-workgroup visibility") - the
+// caller refuses it there, see PeerExchange::Create.
+enum WindowMemory { kWindowUncached = 0, kWindowFineGrained = 1, kWindowPlain = 2 };
+
+void* AllocWindow(size_t bytes, WindowMemory* kind) {
   void* p = nullptr;
+  const char* force = std::getenv("EPSILON_HIP_PEER_WINDOW_MEMORY");  // tests: "plain"
+  const bool plain_only = force && std::strcmp(force, "plain") == 0;
+  if (!plain_only) {
 #ifdef hipDeviceMallocUncached
-  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess && p) return p;
-  (void)hipGetLastError();
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess && p) {
+      *kind = kWindowUncached;
+      return p;
+    }
+    (void)hipGetLastError();
 #endif
-  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess && p) return p;
-  (void)hipGetLastError();
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess && p) {
+      *kind = kWindowFineGrained;
+      return p;
+    }
+    (void)hipGetLastError();
+  }
   EPS_HIP(hipMalloc(&p, bytes));
+  *kind = kWindowPlain;
   return p;
+}
+
+// Identity of the physical device this process drives, as 16 bytes (the PCI bus id string,
+// "0000:05:00.0"): two ranks with equal bytes share one GPU.
+void DeviceIdentity(int device, unsigned char out[16]) {
+  char bus[64] = {0};
+  std::memset(out, 0, 16);
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) {
+    (void)hipGetLastError();
+    std::snprintf(bus, sizeof(bus), "ordinal:%d", device);
+  }
+  std::memcpy(out, bus, std::min<size_t>(16, std::strlen(bus)));
 }
 
 }  // namespace
@@ -220,16 +250,20 @@ PeerExchange* PeerExchange::Create(Comm* comm, int64_t slot_floats, int rehearse
   v.rehearse = rehearse ? 1 : 0;
   v.slot = (slot_floats + 63) / 64 * 64;
   for (int q = 0; q < PeerView::kMaxPeers; ++q) v.win[q] = nullptr;
+  // per rank: the IPC handle, 16 bytes of device identity, 1 byte of window memory kind
   constexpr int HB = static_cast<int>(sizeof(hipIpcMemHandle_t));
+  constexpr int XB = HB + 16 + 1;
   const bool shared = !rehearse && comm->size() > 1;
-  std::vector<double> enc(HB, 0.0);
+  std::vector<double> enc(XB, 0.0);
   std::string err;
+  WindowMemory mem_kind = kWindowPlain;
   // step 1 (local): window, epoch counter, error word, IPC handle
   try {
-    // [channel][source rank][slot] granules, then one 256-byte line for the epoch counter
-    const size_t granules = static_cast<size_t>(kChannels) * G * v.slot;
+    // [channel][epoch parity][source rank][slot] granules, then one 256-byte line for the epoch
+    // counter (kernels_peer.hip: why every slot exists twice)
+    const size_t granules = static_cast<size_t>(kChannels) * 2 * G * v.slot;
     px->bytes_ = granules * sizeof(unsigned long long) + 256;
-    px->local_ = AllocWindow(px->bytes_);
+    px->local_ = AllocWindow(px->bytes_, &mem_kind);
     EPS_HIP(hipMemset(px->local_, 0, px->bytes_));
     v.epoch = reinterpret_cast<unsigned*>(static_cast<char*>(px->local_) +
                                           granules * sizeof(unsigned long long));
@@ -243,6 +277,10 @@ PeerExchange* PeerExchange::Create(Comm* comm, int64_t slot_floats, int rehearse
       EPS_HIP(hipIpcGetMemHandle(&mine, px->local_));
       const unsigned char* mb = reinterpret_cast<const unsigned char*>(&mine);
       for (int i = 0; i < HB; ++i) enc[i] = mb[i];
+      unsigned char ident[16];
+      DeviceIdentity(rt.device(), ident);
+      for (int i = 0; i < 16; ++i) enc[HB + i] = ident[i];
+      enc[HB + 16] = static_cast<double>(mem_kind);
     }
   } catch (const std::exception& e) {
     err = e.what();
@@ -257,17 +295,38 @@ PeerExchange* PeerExchange::Create(Comm* comm, int64_t slot_floats, int rehearse
   } else {
     // exchange the handles: one float per byte (exact under the sum-with-zeros all-gather of
     // the host-callback backend, which would not preserve arbitrary bit patterns)
-    DVec send = DVec::FromHost(enc.data(), HB, F32);
-    DVec recv = DVec::Zeros(static_cast<int64_t>(HB) * G, F32);
-    comm->AllGather(send.data(), recv.data(), HB, F32);
+    DVec send = DVec::FromHost(enc.data(), XB, F32);
+    DVec recv = DVec::Zeros(static_cast<int64_t>(XB) * G, F32);
+    comm->AllGather(send.data(), recv.data(), XB, F32);
     rt.Sync();
     if (!AllRanksOk(comm, err.empty())) {
       if (why) *why = err.empty() ? "a peer rank could not create its window" : err;
       return nullptr;
     }
+    std::vector<double> all = recv.ToHost();
+    // A window in plain (coarse-grained) device memory may only be polled from its own device:
+    // every rank sees the same table, so every rank reaches the same verdict without a vote.
+    for (int q = 0; q < G && err.empty(); ++q) {
+      if (static_cast<int>(all[static_cast<size_t>(q) * XB + HB + 16]) != kWindowPlain) continue;
+      for (int r = 0; r < G; ++r) {
+        bool same = true;
+        for (int i = 0; i < 16; ++i)
+          same = same && all[static_cast<size_t>(q) * XB + HB + i] == all[static_cast<size_t>(r) * XB + HB + i];
+        if (!same) {
+          std::ostringstream os;
+          os << "rank " << q << " could only get plain hipMalloc memory for its window and rank " << r
+             << " sits on a different device: a plain window polled across devices may serve stale lines";
+          err = os.str();
+          break;
+        }
+      }
+    }
+    if (!err.empty()) {
+      if (why) *why = err;
+      return nullptr;
+    }
     // step 2: map the peers' windows
     try {
-      std::vector<double> all = recv.ToHost();
       for (int q = 0; q < G; ++q) {
         if (q == v.rank) {
           v.win[q] = static_cast<unsigned long long*>(px->local_);
@@ -276,7 +335,7 @@ PeerExchange* PeerExchange::Create(Comm* comm, int64_t slot_floats, int rehearse
         hipIpcMemHandle_t h;
         unsigned char* hb = reinterpret_cast<unsigned char*>(&h);
         for (int i = 0; i < HB; ++i)
-          hb[i] = static_cast<unsigned char>(all[static_cast<size_t>(q) * HB + i]);
+          hb[i] = static_cast<unsigned char>(all[static_cast<size_t>(q) * XB + i]);
         void* p = nullptr;
         EPS_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
         px->opened_.push_back(p);

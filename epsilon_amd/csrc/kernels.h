@@ -136,6 +136,8 @@ void MatCopy(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& s
              int64_t lds, const DVec& dst);
 // W[i,i] += alpha (d undefined) or W[i,i] += alpha*d[i]
 void AddDiag(const DVec& W, int64_t n, int64_t ld, double alpha, const DVec* d);
+// colsum_dev[j] = sum_i |A(i, j)| as device doubles (max_j = the 1-norm of A): condition estimates
+void ColAbsSums(const DVec& A, int64_t rows, int64_t cols, int64_t lda, double* colsum_dev);
 // dst (mA*mB x nA*nB) = kron(A, B), all column-major contiguous
 void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVec& B,
                int64_t mB, int64_t nB);

@@ -20,9 +20,14 @@
 // the data is its own flag: no fence between payload and flag, no ordering assumption on the
 // fabric (MI355X_MICROARCH.md, Valid forms, R2).  tag = 2*epoch + phase, epoch = a device counter
 // the fused pass increments once per sweep - kernel arguments are frozen when the sweep is
-// replayed from a hipGraph, the counter is not.  A slot is written again only after two further
-// exchanges have completed, each of which the writer could only pass once the reader had finished
-// the kernel that read the slot (stream order), so one buffer per channel suffices.
+// replayed from a hipGraph, the counter is not.  Every (channel, source) slot exists TWICE, indexed by
+// the parity of the epoch: a writer reaches epoch t + 2 - the next use of the same buffer - only
+// after it has passed its poll of epoch t + 1 on that channel, i.e. after the reader has launched the
+// kernel that pushes for epoch t + 1, which stream order puts behind the reader's kernel of epoch t
+// that read the buffer.  (With ONE buffer per channel that argument needs a second exchange per
+// sweep between two uses; a sweep with the replicated inverse apply - 2 ranks, or
+// EPSILON_HIP_SHARDED_APPLY=r - has only the reduce exchange, and a delayed reader could then find
+// its granule already overwritten with tag t + 1 and time out.)
 //
 // Every poll is bounded (kTimeoutTicks of the 100 MHz constant clock): a missing peer ends in an
 // error word, never in a hung grid.  Waiting happens only in these two small kernels, never in the
@@ -68,61 +73,17 @@ __device__ inline void ReportTimeout(const PeerView& pv, unsigned code) {
   __hip_atomic_store(pv.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// address of granule i of (channel, source) in the window of rank `dest`
-__device__ inline u64* Slot(const PeerView& pv, int dest, int channel, int source, long long i) {
-  return pv.win[dest] + (static_cast<long long>(channel) * pv.G + source) * pv.slot + i;
+// address of granule i of (channel, epoch parity, source) in the window of rank `dest`
+__device__ inline u64* Slot(const PeerView& pv, int dest, int channel, unsigned epoch, int source,
+                            long long i) {
+  return pv.win[dest] +
+         ((static_cast<long long>(channel) * 2 + (epoch & 1u)) * pv.G + source) * pv.slot + i;
 }
 
-// Push one value into (channel, i) of every rank's window, this rank's own included.
-__device__ inline void PushAll(const PeerView& pv, int channel, long long i, unsigned tag, float v) {
-  const u64 g = Granule(tag, v);
-#pragma unroll
-  for (int q = 0; q < PeerView::kMaxPeers; ++q) {
-    if (q < pv.G) PushGranule(Slot(pv, q, channel, pv.rehearse ? q : pv.rank, i), g);
-  }
-}
-
-// Wait for the E consecutive granules i .. i+E-1 of (channel, source q) for every q < G; returns
-// the values.  All E*G loads of a round are issued together; lanes whose granules have all arrived
-// leave the loop.
-template <int E>
-__device__ inline bool PollAll(const PeerView& pv, int channel, long long i, unsigned tag,
-                               float (&val)[E][PeerView::kMaxPeers], unsigned code) {
+__device__ inline bool PollOne(const PeerView& pv, int channel, unsigned epoch, int source,
+                               long long i, unsigned tag, float* val, unsigned code) {
   const u64 t0 = wall_clock64();
-  for (;;) {
-    u64 x[E][PeerView::kMaxPeers];
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-#pragma unroll
-      for (int q = 0; q < PeerView::kMaxPeers; ++q)
-        x[e][q] = q < pv.G ? LoadGranule(Slot(pv, pv.rank, channel, q, i + e)) : 0;
-    bool ok = true;
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-#pragma unroll
-      for (int q = 0; q < PeerView::kMaxPeers; ++q) {
-        if (q < pv.G) {
-          ok = ok && static_cast<unsigned>(x[e][q] >> 32) == tag;
-          val[e][q] = __uint_as_float(static_cast<unsigned>(x[e][q]));
-        }
-      }
-    if (ok) return true;
-    if (Failed(pv) || wall_clock64() - t0 > kTimeoutTicks) {
-      ReportTimeout(pv, code);
-#pragma unroll
-      for (int e = 0; e < E; ++e)
-#pragma unroll
-        for (int q = 0; q < PeerView::kMaxPeers; ++q) val[e][q] = 0.0f;
-      return false;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-
-__device__ inline bool PollOne(const PeerView& pv, int channel, int source, long long i,
-                               unsigned tag, float* val, unsigned code) {
-  const u64 t0 = wall_clock64();
-  const u64* g = Slot(pv, pv.rank, channel, source, i);
+  const u64* g = Slot(pv, pv.rank, channel, epoch, source, i);
   for (;;) {
     const u64 x = LoadGranule(g);
     if (static_cast<unsigned>(x >> 32) == tag) {
@@ -210,14 +171,15 @@ __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
     mine_s[t] = alpha * (((av + bv) + cv) + dv);
   }
   __syncthreads();
-  const unsigned tag = 2u * (*pv.epoch) + 1u;
+  const unsigned epoch = *pv.epoch;
+  const unsigned tag = 2u * epoch + 1u;
   {
     const int row = t & (kRQ * 4 - 1), q = t >> 5;  // kRQ * 4 == 32
     const long long r = rbase + row;
     if (q < pv.G && r < rows) {
-      PushGranule(Slot(pv, q, 0, pv.rehearse ? q : pv.rank, r), Granule(tag, mine_s[row]));
+      PushGranule(Slot(pv, q, 0, epoch, pv.rehearse ? q : pv.rank, r), Granule(tag, mine_s[row]));
       float v;
-      PollOne(pv, 0, q, r, tag, &v, 1u);
+      PollOne(pv, 0, epoch, q, r, tag, &v, 1u);
       got[q][row] = v;
     }
   }
@@ -244,7 +206,8 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
   // the m floats in LDS first cost a third of the kernel's traffic)
   __shared__ float red[kBlock / 64][CP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned tag = 2u * (*pv.epoch) + 2u;
+  const unsigned epoch = *pv.epoch;
+  const unsigned tag = 2u * epoch + 2u;
   const long long npass = (slab + CP - 1) / CP;
   const long long nvec = m / 4;
   for (long long pass = blockIdx.x; pass < npass; pass += gridDim.x) {
@@ -298,7 +261,7 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
       const int c = threadIdx.x % CP, q = threadIdx.x / CP;
       if (j0 + c < slab && q < pv.G) {
         const float t = scale * (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
-        PushGranule(Slot(pv, q, 1, pv.rehearse ? q : pv.rank, j0 + c), Granule(tag, t));
+        PushGranule(Slot(pv, q, 1, epoch, pv.rehearse ? q : pv.rank, j0 + c), Granule(tag, t));
         // the own slab goes straight into w: no workgroup of this grid ever waits for another
         // workgroup of the same grid, only for other GPUs
         if (q == 0 && !pv.rehearse) wpad[static_cast<long long>(pv.rank) * slab + j0 + c] = t;
@@ -314,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
     if (q == pv.rank && !pv.rehearse) continue;
     const long long j = g - q * slab;
     float v;
-    PollOne(pv, 1, q, j, tag, &v, 2u);
+    PollOne(pv, 1, epoch, q, j, tag, &v, 2u);
     wpad[g] = v;
   }
 }

@@ -275,6 +275,23 @@ __global__ __launch_bounds__(kBlock) void SymmetrizeKernel(T* C, int64_t n, int6
   }
 }
 
+// colsum[j] = sum_i |A[i + j*lda]| (fp64): the 1-norm of a matrix is the largest of these.  One
+// workgroup per column, the column is contiguous.
+template <class T>
+__global__ __launch_bounds__(kBlock) void ColAbsSumKernel(const T* __restrict__ A, int64_t rows,
+                                                          int64_t lda, double* __restrict__ colsum) {
+  const T* col = A + static_cast<int64_t>(blockIdx.x) * lda;
+  double a0 = 0, a1 = 0;
+  int64_t i = threadIdx.x;
+  for (; i + kBlock < rows; i += 2 * kBlock) {
+    a0 += fabs(static_cast<double>(col[i]));
+    a1 += fabs(static_cast<double>(col[i + kBlock]));
+  }
+  if (i < rows) a0 += fabs(static_cast<double>(col[i]));
+  const double total = BlockSum(a0 + a1);
+  if (threadIdx.x == 0) colsum[blockIdx.x] = total;
+}
+
 template <class T>
 __global__ __launch_bounds__(kBlock) void KronKernel(T* __restrict__ dst, const T* __restrict__ A,
                                                      int64_t mA, int64_t nA,
@@ -413,6 +430,13 @@ void SymmetrizeFromLower(const DVec& C, int64_t n, int64_t ldc) {
   unsigned nb = static_cast<unsigned>((n + 31) / 32);
   EPS_DISPATCH(C.dt, hipLaunchKernelGGL(SymmetrizeKernel<T>, dim3(nb, nb), dim3(kBlock), 0,
                                         Runtime::Get().stream(), C.as<T>(), n, ldc));
+}
+
+void ColAbsSums(const DVec& A, int64_t rows, int64_t cols, int64_t lda, double* colsum_dev) {
+  if (rows <= 0 || cols <= 0) return;
+  EPS_CHECK(A.n >= (cols - 1) * lda + rows);
+  EPS_DISPATCH(A.dt, hipLaunchKernelGGL(ColAbsSumKernel<T>, dim3(static_cast<unsigned>(cols)), dim3(kBlock), 0,
+                                        Runtime::Get().stream(), A.as<T>(), rows, lda, colsum_dev));
 }
 
 void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVec& B,

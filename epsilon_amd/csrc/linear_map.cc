@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <sstream>
 
 #include "comm.h"
@@ -909,6 +910,63 @@ std::vector<double> GetDiagonal(const LinearMap& A) {
 double GetScalar(const LinearMap& A) {
   EPS_CHECK_MSG(A.impl().type() == SCALAR_MATRIX, "Non-scalar matrix " << A.impl().DebugString());
   return static_cast<const ScalarMatrixImpl&>(A.impl()).alpha();
+}
+
+// ||A||_1 (largest absolute column sum) of a symmetric block; for the transposed view of a dense
+// buffer this is the infinity norm of the map - equal for the symmetric pivot blocks this is used on.
+double OneNorm(const LinearMapImpl& A) {
+  switch (A.type()) {
+    case SCALAR_MATRIX: return std::fabs(static_cast<const ScalarMatrixImpl&>(A).alpha());
+    case DIAGONAL_MATRIX: {
+      double mx = 0;
+      for (double d : static_cast<const DiagonalMatrixImpl&>(A).diagonal()) mx = std::max(mx, std::fabs(d));
+      return mx;
+    }
+    case DENSE_MATRIX: {
+      const auto& D = static_cast<const DenseMatrixImpl&>(A);
+      if (D.rows() == 0 || D.cols() == 0) return 0;
+      auto buf = Runtime::Get().Alloc(static_cast<size_t>(D.cols()) * sizeof(double));
+      k::ColAbsSums(D.data(), D.rows(), D.cols(), D.rows(), static_cast<double*>(buf->p));
+      std::vector<double> h(static_cast<size_t>(D.cols()));
+      EPS_HIP(hipMemcpyAsync(h.data(), buf->p, h.size() * sizeof(double), hipMemcpyDeviceToHost,
+                             Runtime::Get().stream()));
+      Runtime::Get().Sync();
+      double mx = 0;
+      for (double v : h) mx = std::max(mx, v);
+      return mx * std::fabs(D.scale());
+    }
+    case SPARSE_MATRIX: {
+      const auto& S = static_cast<const SparseMatrixImpl&>(A);
+      const HostCsc& C = S.csc_unscaled();
+      double mx = 0;
+      for (int64_t j = 0; j < C.n; ++j) {
+        double sum = 0;
+        for (int32_t p = C.colptr[j]; p < C.colptr[j + 1]; ++p) sum += std::fabs(C.val[p]);
+        mx = std::max(mx, sum);
+      }
+      return mx * std::fabs(S.scale());
+    }
+    case KRONECKER_PRODUCT: {
+      const auto& K = static_cast<const KroneckerProductImpl&>(A);
+      return OneNorm(K.A().impl()) * OneNorm(K.B().impl());
+    }
+    default: return 0;
+  }
+}
+
+double ConditionEstimate(const LinearMap& B, const LinearMap& Binv) {
+  if (B.impl().type() == SCALAR_MATRIX) return 1.0;
+  if (B.impl().type() == DIAGONAL_MATRIX) {
+    // zero entries stay zero in the reference's inverse (diagonal_matrix_impl.cc:19-21): not counted
+    double mx = 0, mn = std::numeric_limits<double>::infinity();
+    for (double d : static_cast<const DiagonalMatrixImpl&>(B.impl()).diagonal()) {
+      if (d == 0) continue;
+      mx = std::max(mx, std::fabs(d));
+      mn = std::min(mn, std::fabs(d));
+    }
+    return mx > 0 ? mx / mn : 1.0;
+  }
+  return OneNorm(B.impl()) * OneNorm(Binv.impl());
 }
 
 ImplType ComputeType(ImplType A, ImplType B) {  // linear_map.cc:141-149

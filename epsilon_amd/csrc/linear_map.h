@@ -133,6 +133,12 @@ LinearMap BuildLinearMap(const pb::LinearMap& proto, DataMap* data);
 std::vector<double> GetDiagonal(const LinearMap& A);  // linear_map.cc:118-129
 double GetScalar(const LinearMap& A);                 // linear_map.cc:131-139
 
+// 1-norm of a (symmetric) map and kappa_1 = ||B||_1 ||B^-1||_1 of a pivot block given its explicit
+// inverse (no reference counterpart: the reference factors in fp64 and never asks; the fp32 mode
+// uses it to decide on iterative refinement of the block solve, block.cc).
+double OneNorm(const LinearMapImpl& A);
+double ConditionEstimate(const LinearMap& B, const LinearMap& Binv);
+
 // Fill model of the block elimination (reference linear/linear_map.cc:141-164).
 ImplType ComputeType(ImplType A, ImplType B);
 uint64_t Nonzeros(ImplType type, uint64_t m, uint64_t n);

@@ -472,6 +472,8 @@ class SumSquareProx final : public ProxOperator {
   // dense.  Then Solve(b_ + v)[var] = v_c + kappa * A^T (Dinv_arg (rhs_arg + kappa * A v_c)).
   bool DescribeLeastSquares(LeastSquaresDesc* d) const override {
     const std::vector<std::string>& p = chol_.order();
+    // a refined solve is not the closed form below (fp32 on ill-conditioned data: block.cc)
+    if (chol_.refine_steps() > 0) return false;
     if (p.size() == 2 && var_keys_.size() == 1) {
       // Two-block driver: A = I on the term's own variable, whose id is then both a column and a
       // row key (prox_admm_two_block.cc:70-75), so the KKT matrix has the two keys [var, arg],

@@ -72,7 +72,15 @@ const char* eps_version(void);
 /* Options (all optional): "dtype" = "f32" (default) | "f64"  compute type of subsequent solves
  * (env EPSILON_HIP_DTYPE);  "device" = ordinal, before first use (env EPSILON_HIP_DEVICE /
  * LOCAL_RANK).  Rides outside SolverParams because the frontend passes only its own kwargs
- * (reference python/epopt/cvxpy_solver.py:69). */
+ * (reference python/epopt/cvxpy_solver.py:69).
+ * "refine" = "auto" (default) | "<steps>"  fp32 mode only: iterative refinement of the block
+ * LDL^T solve behind SUM_SQUARE / ZERO / AFFINE.  The elimination inverts its pivot blocks
+ * explicitly (reference vector/block_cholesky.cc:119-133, linear/dense_matrix_impl.cc:21-30); in
+ * fp64, as the reference runs, that is harmless, in fp32 the forward error is kappa * 6e-8 per
+ * solve.  "auto" estimates kappa_1 of every pivot block at Init and adds 1 / 2 / 3 refinement
+ * steps (residual against the blocks as given) above 1e3 / 3e4 / 3e6; below 1e3 - every
+ * BASELINE.json lasso - the solve is the reference's sequence of operations unchanged.
+ * "0" switches it off (env EPSILON_HIP_REFINE). */
 int eps_set_option(const char* key, const char* value);
 /* Number of visible HIP devices (0 if none); never fails. */
 int eps_device_count(void);
@@ -102,8 +110,11 @@ void eps_result_free(eps_result* r);
 /* ---- solver handles: warm start, staged runs, timing --------------------------------------- */
 /* Replaces the process-global warm-start cache (solvemodule.cc:22,142-156): the caller keeps the
  * handle, so the data matrix, the cached factorisation and x/y/u stay resident in HBM across
- * calls.  Host blobs are copied by create / set_parameter (free them when the call returns; a
- * copy of 64 MB or more is released again once the matrix is resident in HBM); device blobs are
+ * calls.  Host blobs are copied by create / set_parameter (free them when the call returns); the
+ * copy lives until eps_solver_destroy, as the reference's DataMap does for the life of its
+ * Solver (solvemodule.cc:58-72) - a re-Init after a parameter change may have to upload it
+ * again - so a handle costs host memory equal to its host blobs (1.9 GB for the 60000 x 4000
+ * feature matrix of BASELINE.json configs[3]) for as long as it is cached; device blobs are
  * borrowed until destroy.  Re-binding a location that is already bound replaces its contents:
  * the next eps_solver_init rebuilds everything that depended on it. */
 int eps_solver_create(const void* problem, size_t problem_len, const void* solver_params,
@@ -172,6 +183,11 @@ int eps_shard_keys(const char* const* keys, size_t nkeys);
  * ranks.  The iterates are those of the single-process solve of the stacked problem
  * (terms f_1..f_G, h; G consensus constraints). */
 int eps_shard_consensus_terms(int on);
+
+/* Largest condition estimate (kappa_1 of a pivot block) and refinement step count of the block
+ * factorisations set up since the last reset (fp32 mode; see the "refine" option).  Either
+ * pointer may be NULL; reset != 0 clears the record afterwards.  Diagnostics / tests. */
+int eps_block_solve_stats(double* max_condition, int* max_refine_steps, int reset);
 
 /* ---- live kernel timing ---------------------------------------------------------------------- */
 /* When enabled, every hot kernel launch is bracketed by HIP events on the solver's stream.

@@ -12,11 +12,15 @@
 //   ref_gram_svd     SelfAdjointEigenSolver(Y^T Y + 1e-15 I), sqrt, U = Y V diag(1/d) [1/0 -> 0]
 //                                                     as prox/ortho_invariant.cc:36-50
 //   ref_llt_solve    Eigen::LLT solve, the check of vector/block_cholesky_test.cc:95-103
+//   ref_lasso_sweeps the unrolled lasso sweep (oracle/lasso_sweep.c) with its three mat-vecs through
+//                    dgemv_: what bench.py times as the reference's CPU path
 //
 // (The reference links the system's -lblas, Makefile:46; Eigen's own BLAS is the one implementation
 // of that interface its tree carries.)  tests/test_oracle_ref.py pins the numpy oracle's dense
 // kernels against these; bench.py may use ref_dgemv as the CPU baseline's mat-vec.
 #include <Eigen/Dense>
+
+#include <cmath>
 
 extern "C" {
 // declarations as in the reference's linear/lapack.h
@@ -40,6 +44,43 @@ void ref_dgemm(char transa, char transb, int m, int n, int k, const double* A, c
   double alpha = 1, beta = 0;
   dgemm_(&transa, &transb, &m, &n, &k, &alpha, const_cast<double*>(A), &lda, const_cast<double*>(B),
          &ldb, &beta, C, &m);
+}
+
+// k sweeps of the compiled lasso (no stopping test) with the three mat-vecs of a sweep going
+// through the reference tree's dgemv_ the way the reference's solver reaches them: forward
+// substitution t = A v ('N'), the cached explicit inverse w = Minv (b - t) (a dense map applied
+// with 'N', dense_matrix_impl.cc:55-67), back substitution g = A^T w ('T')
+// (vector/block_cholesky.cc:86-117, 135-137); the elementwise steps between them are those of
+// oracle/lasso_sweep.c (prox_admm.cc:135-147, scaled_zone.cc:90-101).  bench.py's cpu_baseline
+// times THIS: one thread, the BLAS of the reference's own tree.  Scratch: t, w (m), g (n).
+void ref_lasso_sweeps(int m, int n, const double* A, const double* Minv, const double* b, double lam,
+                      double* x0, double* x1, double* u, double* y0, double* y1, int k, double* t,
+                      double* w, double* g) {
+  for (int it = 0; it < k; ++it) {
+    for (int j = 0; j < n; ++j) u[j] = (u[j] - y0[j]) - y1[j];
+    for (int j = 0; j < n; ++j) u[j] += y0[j];
+    ref_dgemv('N', m, n, A, u, t);
+    for (int i = 0; i < m; ++i) t[i] = b[i] - t[i];
+    ref_dgemv('N', m, m, Minv, t, w);
+    ref_dgemv('T', m, n, A, w, g);
+    for (int j = 0; j < n; ++j) {
+      x0[j] = u[j] + 2.0 * g[j];
+      y0[j] = x0[j];
+      u[j] -= y0[j];
+    }
+    for (int j = 0; j < n; ++j) {
+      u[j] += y1[j];
+      const double v = -u[j];
+      double x;
+      if (std::fabs(v) <= 0) x = v;
+      else if (v > lam) x = v - lam;
+      else if (v < -lam) x = v + lam;
+      else x = 0;
+      x1[j] = x;
+      y1[j] = -x;
+      u[j] -= y1[j];
+    }
+  }
 }
 
 // returns 0 on Eigen::Success

@@ -83,3 +83,17 @@ def gram_svd(Y):
     if lib().ref_gram_svd(ctypes.c_int(m), ctypes.c_int(n), _p(Y), _p(d), _p(V), _p(U)) != 0:
         raise ArithmeticError("Eigen::SelfAdjointEigenSolver did not succeed")
     return d, V, U
+
+
+def lasso_sweeps(A, Minv, b, lam, state, k):
+    """k sweeps of the compiled lasso on `state` (c_oracle.LassoState) with the mat-vecs through the
+    reference tree's dgemv_ (ref_driver.cc: ref_lasso_sweeps); no stopping test."""
+    m, n = A.shape
+    assert A.flags.f_contiguous and Minv.flags.f_contiguous and A.dtype == np.float64
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    t, w, g = np.empty(m), np.empty(m), np.empty(n)
+    lib().ref_lasso_sweeps(ctypes.c_int(m), ctypes.c_int(n), _p(A), _p(Minv), _p(b), ctypes.c_double(lam),
+                           _p(state.x0), _p(state.x1), _p(state.u), _p(state.y0), _p(state.y1),
+                           ctypes.c_int(k), _p(t), _p(w), _p(g))
+    state.iter += k
+    return k

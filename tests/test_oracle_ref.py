@@ -77,6 +77,29 @@ def test_block_ldl_solve_vs_reference_llt():
     np.testing.assert_allclose(got, ref_lib.llt_solve(Kd, b), rtol=1e-10, atol=1e-12)
 
 
+def test_lasso_sweep_through_reference_blas_matches_the_oracles():
+    """ref_lasso_sweeps (the unrolled sweep with its three mat-vecs through the reference tree's
+    dgemv_: what bench.py times as the reference's CPU path) against the plain-C restatement and the
+    generic numpy oracle's own iterates on the same instance."""
+    from oracle import c_oracle
+    from epsilon_amd import wire
+    prob, info = problems.lasso(40, 90, seed=5)
+    A = np.asfortranarray(info["A"], dtype=np.float64)
+    b, lam = np.asarray(info["b"], dtype=np.float64).ravel(), float(info["lam"])
+    m, n = A.shape
+    Minv = np.asfortranarray(ref_lib.ldlt_inverse(np.eye(m) + 2 * ref_lib.dgemm(A, A, tb=True)))
+    s_ref, s_c = c_oracle.LassoState(n), c_oracle.LassoState(n)
+    ref_lib.lasso_sweeps(A, Minv, b, lam, s_ref, 11)
+    c_oracle.lasso_run(A, Minv, b, lam, s_c, 11, abs_tol=0, rel_tol=0)
+    for f in ("x0", "x1", "u", "y0", "y1"):
+        np.testing.assert_allclose(getattr(s_ref, f), getattr(s_c, f), rtol=0, atol=1e-12, err_msg=f)
+    # the generic oracle after the same 11 sweeps (stopping rule off)
+    sb = wire.SolverParams(max_iterations=11, abs_tol=0.0, rel_tol=0.0).SerializeToString()
+    _, x = orc.solve(prob.SerializeToString(), [], sb, prob.expression_data())
+    got = np.frombuffer(x[sorted(x)[0]])
+    assert min(np.abs(got - s_ref.x0).max(), np.abs(got - s_ref.x1).max()) < 1e-9
+
+
 @pytest.mark.parametrize("shape", [(6, 6), (12, 7), (20, 20)])
 def test_nuclear_norm_prox_vs_reference_eigensolver(shape):
     """The oracle's nuclear-norm prox against the reference's own route: eigenvectors of
