@@ -73,12 +73,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    s = _solve.Solver(pb, wire.SolverParams(max_iterations=50000).SerializeToString(), data)
+    # the clock starts BEFORE the handle exists: creating it copies the host blobs (the 376 MB data
+    # matrix), work the reference's 38.75 s solve includes (solvemodule.cc:58-72 copies every blob
+    # inside its solve); reported separately and inside time_to_eps_s
     barrier()
     t0 = time.time()
+    s = _solve.Solver(pb, wire.SolverParams(max_iterations=50000).SerializeToString(), data)
+    t_create = time.time() - t0
     s.init()
     barrier()
-    t_init = time.time() - t0
+    t_init = time.time() - t0 - t_create
     s.run(-1)
     barrier()
     t_total = time.time() - t0
@@ -89,9 +93,9 @@ def main():
     if rank == 0:
         print(json.dumps({
             "workload": "multiclass hinge X %dx%d k=%d lam=%g, samples sharded x%d" % (a.m, a.features, a.classes, a.lam, world),
-            "n_gpus": world, "init_s": t_init, "time_to_eps_s": t_total, "sweeps": S.num_iterations + 1,
+            "n_gpus": world, "create_s": t_create, "init_s": t_init, "time_to_eps_s": t_total, "sweeps": S.num_iterations + 1,
             "state": ["NOT_STARTED", "INITIALIZING", "RUNNING", "OPTIMAL", "MAX_ITERATIONS_REACHED", "ERROR"][S.state],
-            "ms_per_sweep": 1e3 * (t_total - t_init) / (S.num_iterations + 1),
+            "ms_per_sweep": 1e3 * (t_total - t_init - t_create) / (S.num_iterations + 1),
             "objective": problems.multiclass_hinge_objective(X, Y, a.lam, Theta),
             "residuals": {"r": S.residuals.r_norm, "s": S.residuals.s_norm, "eps_pri": S.residuals.epsilon_primal,
                           "eps_dual": S.residuals.epsilon_dual},

@@ -2,6 +2,7 @@
 // reference interface it replaces (python/epopt/solvemodule.cc).
 #include "../../include/epsilon_hip.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -598,6 +599,32 @@ int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg) {
       if (i > 0) total += e;
     }
     *ms_avg = total / iters;
+  });
+}
+
+int eps_test_spd_inverse_repeat(int64_t n, int form_a, int form_b, double* diff_fro, double* norm_fro) {
+  return Guard([&] {
+    EPS_CHECK(n > 0 && diff_fro != nullptr && norm_fro != nullptr);
+    const DType dt = ConfiguredDType();
+    DVec G = Synthetic(n * n, dt, 1.0);
+    DVec W0 = DVec::Zeros(n * n, dt);
+    k::Gemm(false, true, n, n, n, 1.0 / n, G, n, G, n, 0.0, W0, n, false);
+    k::AddDiag(W0, n, n, 1.0, nullptr);
+    G = DVec();
+    DVec Xa = W0.Clone(), Xb = W0.Clone();
+    struct Restore { ~Restore() { k::SetPotrfForm(-1); } } restore;
+    k::SetPotrfForm(form_a);
+    k::SpdInverseInPlace(Xa, n);
+    k::SetPotrfForm(form_b);
+    k::SpdInverseInPlace(Xb, n);
+    Runtime& rt = Runtime::Get();
+    rt.ResetSlots();
+    const int s0 = rt.NewSlot(), s1 = rt.NewSlot();
+    k::SumSqDiff(Xa, Xb, rt.SlotPtr(s0), false);
+    k::SumSq(Xa, rt.SlotPtr(s1), false);
+    rt.FetchSlots();
+    *diff_fro = std::sqrt(rt.SlotValue(s0));
+    *norm_fro = std::sqrt(rt.SlotValue(s1));
   });
 }
 

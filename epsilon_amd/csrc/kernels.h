@@ -138,6 +138,8 @@ void MatCopy(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& s
 void AddDiag(const DVec& W, int64_t n, int64_t ld, double alpha, const DVec* d);
 // colsum_dev[j] = sum_i |A(i, j)| as device doubles (max_j = the 1-norm of A): condition estimates
 void ColAbsSums(const DVec& A, int64_t rows, int64_t cols, int64_t lda, double* colsum_dev);
+// y = x / sqrt(*normsq_dev) (device scalar; 0 leaves x unscaled): power-iteration normalisation
+void ScaleByInvNorm(const DVec& y, const DVec& x, const double* normsq_dev);
 // dst (mA*mB x nA*nB) = kron(A, B), all column-major contiguous
 void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVec& B,
                int64_t mB, int64_t nB);
@@ -147,6 +149,9 @@ void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVe
 // W (n x n, ld = n, symmetric positive definite, full storage) -> W^{-1} in place.
 // Blocked Cholesky + triangular inverse + X^T X, all on device.  Throws if a pivot is <= 0.
 void SpdInverseInPlace(const DVec& W, int64_t n);
+// Cholesky step form of the next factorisations: -1 by environment (default), 0 the fused f32 step,
+// 1 the diagonal + panel launches (tests hold the two forms to each other)
+void SetPotrfForm(int form);
 // Columns [lo, lo + cnt) of W^-1 into Out (n x cnt, ld n); W is overwritten by its Cholesky
 // factor.  Cholesky + two blocked triangular solves on the cnt unit columns.
 void SpdInverseColumns(const DVec& W, int64_t n, int64_t lo, int64_t cnt, const DVec& Out);
@@ -236,6 +241,7 @@ void ExpEpigraph(const DVec& x, const DVec& t, const DVec& v, const DVec& s);  /
 // reference prox/total_variation_1d.cc:21 (glmgen tf_dp): exact 1-D TV prox
 void Tv1d(const DVec& x, const DVec& v, double lam);
 int Tv1dLastLevels();  // depth of the level-set recursion of the last Tv1d call
+int Tv1dBinary(const DVec& x, const DVec& v, double lam);  // round-2 form (kernels_tv.hip), returns the depth
 // the same by Johnson's sequential DP on one lane (cross-check of the parallel kernel)
 void Tv1dSerial(const DVec& x, const DVec& v, double lam);
 

@@ -598,6 +598,8 @@ void DoublingInverse(const DVec& W, const DVec& X, int64_t n, const DVec& dinv, 
 
 }
 
+int g_potrf_form = -1;  // -1: by environment, 0: fused step (f32), 1: diagonal + panel launches
+
 void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
   Runtime& rt = Runtime::Get();
   hipStream_t s = rt.stream();
@@ -614,7 +616,9 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
     // rows below it (same update + forward substitution against the new L11) - instead of the
     // diagonal kernel, a copy and two small GEMMs; the 64 x 64 inverses the later stages want are
     // formed for all blocks at once at the end.
-    static const bool two_kernels = std::getenv("EPSILON_HIP_POTRF_TWO_KERNELS") != nullptr;
+    // (read per call: tests compare the two forms in one process, eps_test_spd_inverse_repeat)
+    const bool two_kernels = g_potrf_form == 1 ||
+                             (g_potrf_form < 0 && std::getenv("EPSILON_HIP_POTRF_TWO_KERNELS") != nullptr);
     const unsigned nblk = static_cast<unsigned>((n + NB - 1) / NB);
     const bool fused = dt == F32 && !two_kernels;
     std::shared_ptr<Buffer> dfac_buf;
@@ -664,6 +668,8 @@ void PotrfBlocked(const DVec& W, int64_t n, const DVec& dinv, int* flag) {
 }
 
 }  // namespace
+
+void SetPotrfForm(int form) { g_potrf_form = form; }
 
 // Columns [lo, lo + cnt) of W^-1 (n x cnt, ld n) without forming the rest: Cholesky, then the two
 // triangular solves L Y = E, L^T Z = Y on the cnt unit columns, 64 rows at a time with the

@@ -723,23 +723,13 @@ template <class T> int Tv1dLevelSets(const DVec& xv, const DVec& yv, double lam)
   return level;
 }
 
-int g_last_levels = 0;
-
 }  // namespace
 
-int Tv1dLastLevels() { return g_last_levels; }
-
-void Tv1d(const DVec& x, const DVec& v, double lam) {
-  EPS_CHECK(x.n == v.n && x.dt == v.dt);
-  const int64_t n = x.n;
-  if (n == 0) return;
-  EPS_CHECK_MSG(n < (int64_t(1) << 31) - 1, "tv1d: n must be below 2^31");
-  if (n == 1 || lam == 0) {  // tf_dp's trivial cases
-    Copy(x, v);
-    return;
-  }
-  if (x.dt == F32) g_last_levels = Tv1dLevelSets<float>(x, v, lam);
-  else g_last_levels = Tv1dLevelSets<double>(x, v, lam);
+// The round-2 binary recursion (one threshold per region and level), kept selectable
+// (EPSILON_HIP_TV=binary) as the A/B partner of the three-threshold form in kernels_tv3.hip.
+int Tv1dBinary(const DVec& x, const DVec& v, double lam) {
+  if (x.dt == F32) return Tv1dLevelSets<float>(x, v, lam);
+  return Tv1dLevelSets<double>(x, v, lam);
 }
 
 }  // namespace k

@@ -292,6 +292,17 @@ __global__ __launch_bounds__(kBlock) void ColAbsSumKernel(const T* __restrict__ 
   if (threadIdx.x == 0) colsum[blockIdx.x] = total;
 }
 
+// y = x / sqrt(*normsq) with the norm read from a device slot (no host round trip): the
+// normalisation step of a power iteration.  *normsq == 0 leaves x unscaled.
+template <class T>
+__global__ __launch_bounds__(kBlock) void ScaleByInvNormKernel(T* __restrict__ y, const T* __restrict__ x,
+                                                               int64_t n, const double* normsq) {
+  const double nn = *normsq;
+  const T sc = nn > 0.0 ? static_cast<T>(1.0 / sqrt(nn)) : T(1);
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n; i += stride) y[i] = sc * x[i];
+}
+
 template <class T>
 __global__ __launch_bounds__(kBlock) void KronKernel(T* __restrict__ dst, const T* __restrict__ A,
                                                      int64_t mA, int64_t nA,
@@ -437,6 +448,13 @@ void ColAbsSums(const DVec& A, int64_t rows, int64_t cols, int64_t lda, double* 
   EPS_CHECK(A.n >= (cols - 1) * lda + rows);
   EPS_DISPATCH(A.dt, hipLaunchKernelGGL(ColAbsSumKernel<T>, dim3(static_cast<unsigned>(cols)), dim3(kBlock), 0,
                                         Runtime::Get().stream(), A.as<T>(), rows, lda, colsum_dev));
+}
+
+void ScaleByInvNorm(const DVec& y, const DVec& x, const double* normsq_dev) {
+  CheckSame(y, x);
+  if (y.n == 0) return;
+  EPS_DISPATCH(y.dt, hipLaunchKernelGGL(ScaleByInvNormKernel<T>, dim3(GridFor(y.n)), dim3(kBlock), 0,
+                                        Runtime::Get().stream(), y.as<T>(), x.as<T>(), y.n, normsq_dev));
 }
 
 void KronDense(const DVec& dst, const DVec& A, int64_t mA, int64_t nA, const DVec& B,

@@ -77,9 +77,11 @@ const char* eps_version(void);
  * LDL^T solve behind SUM_SQUARE / ZERO / AFFINE.  The elimination inverts its pivot blocks
  * explicitly (reference vector/block_cholesky.cc:119-133, linear/dense_matrix_impl.cc:21-30); in
  * fp64, as the reference runs, that is harmless, in fp32 the forward error is kappa * 6e-8 per
- * solve.  "auto" estimates kappa_1 of every pivot block at Init and adds 1 / 2 / 3 refinement
- * steps (residual against the blocks as given) above 1e3 / 3e4 / 3e6; below 1e3 - every
- * BASELINE.json lasso - the solve is the reference's sequence of operations unchanged.
+ * solve.  "auto" estimates the condition of every pivot block at Init (kappa_1 from two passes
+ * over the block and its inverse; where that exceeds 1e3, kappa_2 from six power iterations on
+ * each) and adds 1 / 2 / 3 refinement steps (residual against the blocks as given) above
+ * 1e3 / 3e4 / 3e6; below 1e3 - every BASELINE.json lasso - the solve is the reference's
+ * sequence of operations unchanged.
  * "0" switches it off (env EPSILON_HIP_REFINE). */
 int eps_set_option(const char* key, const char* value);
 /* Number of visible HIP devices (0 if none); never fails. */
@@ -184,7 +186,7 @@ int eps_shard_keys(const char* const* keys, size_t nkeys);
  * (terms f_1..f_G, h; G consensus constraints). */
 int eps_shard_consensus_terms(int on);
 
-/* Largest condition estimate (kappa_1 of a pivot block) and refinement step count of the block
+/* Largest condition estimate of a pivot block and refinement step count of the block
  * factorisations set up since the last reset (fp32 mode; see the "refine" option).  Either
  * pointer may be NULL; reset != 0 clears the record afterwards.  Diagnostics / tests. */
 int eps_block_solve_stats(double* max_condition, int* max_refine_steps, int reset);
@@ -232,6 +234,12 @@ int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, in
 /* SPD inverse of an n x n synthetic matrix. */
 int eps_bench_spd_inverse(int64_t n, int iters, double* ms_avg);
 int eps_bench_spd_inverse_columns(int64_t n, int64_t cnt, int iters, double* ms_avg);
+/* Test entry: the explicit inverse (reference linear/dense_matrix_impl.cc:21-30) of one synthetic
+ * n x n positive definite matrix computed twice, with the Cholesky step in form_a and form_b
+ * (0 = the fused step of the f32 mode, 1 = separate diagonal / panel launches, -1 = default):
+ * ||X_a - X_b||_F and ||X_a||_F.  form_a == form_b checks run-to-run determinism (a data race
+ * between the workgroups of a launch shows as a non-zero difference, above all on a busy GPU). */
+int eps_test_spd_inverse_repeat(int64_t n, int form_a, int form_b, double* diff_fro, double* norm_fro);
 
 /* Microbenchmark: average milliseconds of one launch of a standalone elementwise prox kernel on
  * n synthetic elements of the configured dtype - kind 0 scaled-zone (NORM_1) with scalar

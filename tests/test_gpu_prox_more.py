@@ -448,7 +448,8 @@ def test_svd_factors_are_orthogonal_and_reconstruct(solve_mod, n):
         assert d[off + 2] < 2e-3, list(d)   # off-diagonal mass of W^T W
 
 
-@pytest.mark.parametrize("case", ["low_rank_tall", "low_rank_wide", "many_above", "full_rank", "edge_at_threshold"])
+@pytest.mark.parametrize("case", ["low_rank_tall", "low_rank_wide", "many_above", "full_rank", "edge_at_threshold",
+                                  "edge_just_above"])
 def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
     """From 512 columns / rows the nuclear-norm prox first tries the leading singular block alone
     (randomized subspace iteration + Jacobi on the small problem, certified by the residuals of
@@ -467,8 +468,13 @@ def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
         m, n, r, noise, lam = 800, 800, 70, 0.01, 2.0
     elif case == "full_rank":
         m, n, r, noise, lam = 640, 640, 5, 1.0, 3.0     # bulk up to ~50: everything above lambda
-    else:
+    elif case == "edge_at_threshold":
         m, n, r, noise, lam = 700, 640, 8, 0.05, 1.8    # bulk edge 0.05 (sqrt(700) + sqrt(640)) ~ 2.6
+    else:
+        # the top of the noise bulk a few per cent ABOVE the threshold: the power-iteration
+        # certificate of the remainder is a lower bound, so it must not accept here on its
+        # resolution alone (the fp64 tolerance below sees a single value kept out of the result)
+        m, n, r, noise, lam = 700, 640, 8, 0.05, 2.5
     V = rng.randn(m, r) @ rng.randn(r, n) + noise * rng.randn(m, n)
     X = ir.variable(m, n, "var:X")
     e = ir.prox(ProxFunction.NORM_NUCLEAR, X)
@@ -487,7 +493,8 @@ def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
     names = list(tags)
     assert any(t.startswith("partial_svd") for t in names), names
     full = ("block_jacobi_svd:%dx%d" % (m, n)) in names or ("jacobi_svd:%dx%d" % (m, n)) in names
-    assert full == (case in ("full_rank", "edge_at_threshold")), (case, names)
+    if case != "edge_just_above":  # (either route is fine there, the result is what counts)
+        assert full == (case in ("full_rank", "edge_at_threshold")), (case, names)
 
 
 @pytest.mark.parametrize("name", ["max", "sum_largest_9", "log_sum_exp"])
