@@ -33,7 +33,7 @@ DEVICE_SOURCES = [("kernels_vec.hip", ["-ffp-contract=off"]),
                   ("kernels_segprox.hip", ["-ffp-contract=off"]),
                   ("kernels_svd.hip", ["-ffp-contract=off"]),
                   ("kernels_tv.hip", ["-ffp-contract=off"]),
-                  ("kernels_tv3.hip", ["-ffp-contract=off"])]
+                  ("kernels_tv3.hip", ["-ffp-contract=off", "-fno-honor-nans"])]
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
           "-I" + os.path.join(HERE, "..", "include")]

@@ -561,9 +561,19 @@ int eps_bench_gemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, in
                    int iters, double* ms_avg) {
   return Guard([&] {
     const DType dt = ConfiguredDType();
-    DVec A = Synthetic(M * K, dt, 1.0);
+    // EPSILON_HIP_BENCH_RANDOM=1: operands with independent pseudo-random entries instead of the
+    // repeating 1024-value pattern (the Gram product inside a solve multiplies random data and
+    // runs 4.8 ms slower than this microbenchmark on the pattern: is it the data?)
+    const bool rnd = std::getenv("EPSILON_HIP_BENCH_RANDOM") != nullptr;
+    auto operand = [&](int64_t count, uint64_t seed) {
+      if (!rnd) return Synthetic(count, dt, 1.0);
+      DVec v = DVec::Empty(count, dt);
+      k::FillHash(v, seed);
+      return v;
+    };
+    DVec A = operand(M * K, 0xA11CEull);
     // lower_only == 2: SYRK proper, both operands are the same buffer (the Gram product)
-    DVec B = lower_only == 2 ? A : Synthetic(K * N, dt, 1.0);
+    DVec B = lower_only == 2 ? A : operand(K * N, 0xB0Bull);
     DVec C = DVec::Zeros(M * N, dt);
     const int64_t lda = trans_a ? K : M, ldb = trans_b ? N : K;
     *ms_avg = TimeLaunches(iters, [&] {

@@ -50,8 +50,13 @@ namespace k {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kItems = 16;                  // samples per thread
-constexpr int kTile = kBlock * kItems;      // 4096 samples per workgroup
+// samples per thread.  8, not 16: the kernels are bound by the latency of a workgroup's serial
+// chain (loads -> scan -> records -> compose -> scan -> classify -> store) times the workgroups a
+// CU can hold, and the forward apply kernel needs 160 registers at 16 (3 waves per SIMD)
+constexpr int kItems = 8;
+constexpr int kWords = kItems / 4;          // state bytes of a chunk, as 32-bit words
+constexpr int kTile = kBlock * kItems;      // samples per workgroup
+constexpr unsigned kAllItems = (1u << kItems) - 1u;
 constexpr int kDirectTiles = 256;           // up to here: no aggregate-scan launches
 constexpr int32_t kInf = 0x7fffffff;
 constexpr int kHead = 1, kEnd = 2, kDone = 0xFC;
@@ -134,51 +139,39 @@ template <class S> __device__ inline S ShflUp(const S& v, int off) {
 }
 
 // One step of a wave scan on the DPP path of the vector ALU: every 32-bit word of the value moves
-// by the same lane pattern; lanes without a source get their own value back.
-template <int CTRL, int ROW_MASK, class S> __device__ inline S DppMove(const S& v) {
+// by the same lane pattern; lanes without a source (row_shr at the start of a row, rows outside
+// ROW_MASK) receive `none` - the algebra's identity - so the caller combines unconditionally (a
+// select per word and step was a quarter of the forward kernel's instructions).
+template <int CTRL, int ROW_MASK, class S> __device__ inline S DppMove(const S& v, const S& none) {
   constexpr int W = (sizeof(S) + 3) / 4;
-  int w[W] = {};
+  int w[W] = {}, o[W] = {};
   memcpy(w, &v, sizeof(S));
+  memcpy(o, &none, sizeof(S));
 #pragma unroll
-  for (int k = 0; k < W; ++k) w[k] = __builtin_amdgcn_update_dpp(w[k], w[k], CTRL, ROW_MASK, 0xF, false);
-  S o;
-  memcpy(&o, w, sizeof(S));
-  return o;
+  for (int k = 0; k < W; ++k) w[k] = __builtin_amdgcn_update_dpp(o[k], w[k], CTRL, ROW_MASK, 0xF, false);
+  S r;
+  memcpy(&r, w, sizeof(S));
+  return r;
 }
 
-// Inclusive scan over the 64 lanes of a wave, in lane order (Alg::combine(earlier, later)).
+// Inclusive scan over the 64 lanes of a wave, in lane order (Alg::combine(earlier, later)):
+// Hillis-Steele inside the rows of 16 lanes (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into
+// rows 1 / 3 (row_bcast15) and lane 31 into rows 2 and 3 (row_bcast31).
 template <class Alg> __device__ inline typename Alg::S WaveInclusive(typename Alg::S v, int lane) {
   using S = typename Alg::S;
-  const int in_row = lane & 15;
-  {
-    const S up = DppMove<0x111, 0xF>(v);
-    if (in_row >= 1) v = Alg::combine(up, v);
-  }
-  {
-    const S up = DppMove<0x112, 0xF>(v);
-    if (in_row >= 2) v = Alg::combine(up, v);
-  }
-  {
-    const S up = DppMove<0x114, 0xF>(v);
-    if (in_row >= 4) v = Alg::combine(up, v);
-  }
-  {
-    const S up = DppMove<0x118, 0xF>(v);
-    if (in_row >= 8) v = Alg::combine(up, v);
-  }
-  {
-    const S up = DppMove<0x142, 0xA>(v);
-    if ((lane >> 4) & 1) v = Alg::combine(up, v);
-  }
-  {
-    const S up = DppMove<0x143, 0xC>(v);
-    if (lane >= 32) v = Alg::combine(up, v);
-  }
+  (void)lane;
+  const S id = Alg::identity();
+  v = Alg::combine(DppMove<0x111, 0xF>(v, id), v);
+  v = Alg::combine(DppMove<0x112, 0xF>(v, id), v);
+  v = Alg::combine(DppMove<0x114, 0xF>(v, id), v);
+  v = Alg::combine(DppMove<0x118, 0xF>(v, id), v);
+  v = Alg::combine(DppMove<0x142, 0xA>(v, id), v);
+  v = Alg::combine(DppMove<0x143, 0xC>(v, id), v);
   return v;
 }
 
 // Exclusive scan of one value per thread over the workgroup, in thread order.  *total = the
-// workgroup aggregate (the same in every thread).  `lds`: kBlock / 64 values.
+// workgroup aggregate (the same in every thread; nullptr: not wanted).  `lds`: kBlock / 64 values.
 template <class Alg>
 __device__ inline typename Alg::S BlockExclusive(typename Alg::S mine, typename Alg::S* lds,
                                                  typename Alg::S* total) {
@@ -187,11 +180,14 @@ __device__ inline typename Alg::S BlockExclusive(typename Alg::S mine, typename 
   const S incl = WaveInclusive<Alg>(mine, lane);
   if (lane == 63) lds[wave] = incl;
   __syncthreads();
+  // what the waves before this one hold: wave-uniform, so the loop costs scalar control only
   S before = Alg::identity();
   for (int w = 0; w < wave; ++w) before = Alg::combine(before, lds[w]);
-  S tot = lds[0];
-  for (int w = 1; w < kBlock / 64; ++w) tot = Alg::combine(tot, lds[w]);
-  *total = tot;
+  if (total != nullptr) {
+    S tot = lds[0];
+    for (int w = 1; w < kBlock / 64; ++w) tot = Alg::combine(tot, lds[w]);
+    *total = tot;
+  }
   S excl = ShflUp(incl, 1);
   if (lane == 0) excl = Alg::identity();
   excl = Alg::combine(before, excl);
@@ -405,7 +401,7 @@ template <class T> __device__ inline void LoadY(const TvS<T>& s, int64_t c0, T (
   if (s.aligned && c0 + kItems <= s.n) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kItems / 4; ++q) {
         const float4 a = reinterpret_cast<const float4*>(s.y + c0)[q];
         yv[4 * q] = a.x;
         yv[4 * q + 1] = a.y;
@@ -414,7 +410,7 @@ template <class T> __device__ inline void LoadY(const TvS<T>& s, int64_t c0, T (
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < kItems / 2; ++q) {
         const double2 a = reinterpret_cast<const double2*>(s.y + c0)[q];
         yv[2 * q] = a.x;
         yv[2 * q + 1] = a.y;
@@ -426,7 +422,21 @@ template <class T> __device__ inline void LoadY(const TvS<T>& s, int64_t c0, T (
   }
 }
 
-__device__ inline int ByteOf(const unsigned (&w)[4], int k) { return static_cast<int>((w[k >> 2] >> (8 * (k & 3))) & 0xffu); }
+__device__ inline int ByteOf(const unsigned (&w)[kWords], int k) { return static_cast<int>((w[k >> 2] >> (8 * (k & 3))) & 0xffu); }
+__device__ inline void LoadBytes(const uint8_t* p, unsigned (&w)[kWords]) {
+  if constexpr (kWords == 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  } else {
+    static_assert(kWords == 2 || kWords == 4, "8 or 16 samples per thread");
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    w[0] = v.x; w[1] = v.y;
+  }
+}
+__device__ inline void StoreBytes(uint8_t* p, const unsigned (&w)[kWords]) {
+  if constexpr (kWords == 4) *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  else *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+}
 
 // ---- pass 1 / 2: forward clamp-shift scan for the three thresholds --------------------------------
 // MODE 0: reduce (tile aggregates).  MODE 1: apply (classes into the state byte, x of regions that
@@ -442,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void TvClipKernel(TvS<T> s) {
   __shared__ Clip3 lds3[kBlock / 64];
   __shared__ int32_t ldsi[kBlock / 64];
   __shared__ unsigned ldsu[kBlock / 64];
+  __shared__ HeadRec ldsr[kBlock];
   if (LevelIsDead(s)) return;
   const int64_t tile = blockIdx.x;
   const int t = threadIdx.x;
@@ -455,87 +466,105 @@ __global__ __launch_bounds__(kBlock) void TvClipKernel(TvS<T> s) {
   // everything that does not depend on the data is requested first: the tile's bytes and samples,
   // and this thread's share of the other tiles' aggregates (direct mode) or the scanned prefixes
   const int64_t c0 = (tile * kBlock + t) * kItems;
-  const uint4 bw = *reinterpret_cast<const uint4*>(s.st + c0);
+  unsigned w[kWords];
+  LoadBytes(s.st + c0, w);
   T yv[kItems];
   LoadY(s, c0, yv);
   const int32_t lin_part = TilePrefixLoad<MaxAlg>(s.direct ? s.tile_head : s.tile_l_in, tile, s.direct);
-  Clip3 pre_part = Clip3Alg::identity();
-  if (MODE == 1) pre_part = TilePrefixLoad<Clip3Alg>(s.agg_clip, tile, s.direct);
-  const unsigned w[4] = {bw.x, bw.y, bw.z, bw.w};
-  // region head of every sample = running maximum of head positions
+  // The record of the region that reaches into the tile from the left: in scanned mode its head
+  // is known before any data arrives, so the record is requested now (not behind the head scan)
+  HeadRec rec_in = HeadRec{0.0, 0.f, 0u};
+  if (!s.direct && lin_part >= 0) rec_in = s.hrec[lin_part];
+  // region head of every sample = running maximum of head positions.  A thread whose chunk holds
+  // a head fetches that region's record itself and leaves it in LDS for the threads after it, so
+  // no thread gathers a record BEHIND the scan (a second dependent round trip per workgroup).
   int32_t last = -1;
 #pragma unroll
   for (int k = 0; k < kItems; ++k)
     if ((ByteOf(w, k) & kHead) && c0 + k < s.n) last = static_cast<int32_t>(c0 + k);
+  HeadRec rec_last = HeadRec{0.0, 0.f, 0u};
+  if (last >= 0) rec_last = s.hrec[last];
+  ldsr[t] = rec_last;
   int32_t tot_head;
   int32_t l = BlockExclusive<MaxAlg>(last, ldsi, &tot_head);
   const int32_t lin = TilePrefixFinish<MaxAlg>(lin_part, s.direct, ldsi);
+  if (s.direct && lin >= 0) rec_in = s.hrec[lin];
+  HeadRec rec_cur = rec_in;
+  if (l > lin) rec_cur = ldsr[(l - static_cast<int32_t>(tile * kTile)) / kItems];
   l = l > lin ? l : lin;
 
-  double a[kItems];     // tau - y' + 0 (samples that take part); tau (samples whose region is constant)
-  float dl[kItems];
-  unsigned finm = 0, actm = 0;
+  // Straight-line arithmetic from here on (the kernel is bound by instruction issue: ~300 VALU
+  // instructions per sample in its first form).  A sample is described by three numbers:
+  //   av  = tau - y'   (0 for samples that do not take part: finished regions, padding)
+  //   dv  = delta      (0 for those)
+  //   le  = lam, or 0 at a region head and for samples that do not take part:
+  //         appending (av, le) to a map (p, lo, hi) is p += a, lo = a + clip(lo, -le, le), hi
+  //         likewise; with le = 0 that is the constant map a - exactly the head's reset and the
+  //         finished samples' zero map (p is irrelevant once lo = hi).
+  const int nvalid = s.n - c0 >= kItems ? kItems : (s.n - c0 > 0 ? static_cast<int>(s.n - c0) : 0);
+  const double lam = s.lam;
+  // The region a sample belongs to changes at heads; both loops below walk the chunk with the
+  // same few lines instead of keeping per-sample arrays in registers (the apply kernel held 197).
+  struct Region {
+    double tau, dd, sl, sr;
+    bool fin;
+    unsigned crf;
+  };
+  auto region_of = [&](const HeadRec& r) {
+    Region g;
+    g.tau = r.tau;
+    g.dd = static_cast<double>(r.delta);
+    g.sl = lam * static_cast<double>(SideSign(r.flags & 3));
+    g.sr = lam * static_cast<double>(SideSign((r.flags >> 2) & 3));
+    g.fin = (r.flags & 16u) != 0;
+    g.crf = (r.flags >> 2) & 3u;
+    return g;
+  };
+  // sample k: av = tau - y' and dk = delta (0 where the sample does not take part), lek = lam (0 at
+  // a head and where it does not take part), act / fnow = takes part / its region finished a level ago
+  auto sample = [&](int k, Region& g, double* av, double* dk, double* lek, bool* act, bool* fnow) {
+    const int b = ByteOf(w, k);
+    const bool valid = k < nvalid;
+    if (valid && (b & kHead))  // (several heads in one chunk: only the last one's record was fetched ahead)
+      g = region_of(static_cast<int32_t>(c0 + k) == last ? rec_last : s.hrec[c0 + k]);
+    const bool live = valid && (b & kDone) != kDone;  // not finished before this level
+    *act = live && !g.fin;
+    *fnow = live && g.fin;
+    double yp = static_cast<double>(yv[k]);
+    yp -= (b & kHead) ? g.sl : 0.0;
+    yp -= (b & kEnd) ? g.sr : 0.0;
+    *av = *act ? g.tau - yp : 0.0;
+    *dk = *act ? g.dd : 0.0;
+    *lek = (*act && !(b & kHead)) ? lam : 0.0;
+  };
   ClipMap acc[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) acc[j] = ClipMap{0.0, -INFINITY, INFINITY};
-  double tau = 0.0;
-  float delta = 0.f;
-  unsigned flags = 0;
-  int32_t lrec = -2;
-  const double lam = s.lam;
+  {
+    Region g = region_of(rec_cur);
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t i = c0 + k;
-    const int b = ByteOf(w, k);
-    a[k] = 0.0;
-    dl[k] = 0.f;
-    if (i >= s.n) continue;
-    if (b & kHead) l = static_cast<int32_t>(i);
-    if ((b & kDone) == kDone) {
+    for (int k = 0; k < kItems; ++k) {
+      // (finished samples and the padding behind the last sample act as the zero map)
+      double a0, dk, lek;
+      bool act, fnow;
+      sample(k, g, &a0, &dk, &lek, &act, &fnow);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) acc[j] = ClipMap{0.0, 0.0, 0.0};
-      continue;
-    }
-    if (l != lrec) {
-      const HeadRec r = s.hrec[l];
-      tau = r.tau;
-      delta = r.delta;
-      flags = r.flags;
-      lrec = l;
-    }
-    if (flags & 16u) {
-      finm |= 1u << k;
-      a[k] = tau;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) acc[j] = ClipMap{0.0, 0.0, 0.0};
-      continue;
-    }
-    actm |= 1u << k;
-    double yp = static_cast<double>(yv[k]);
-    if (b & kHead) yp -= lam * static_cast<double>(SideSign(flags & 3));
-    if (b & kEnd) {
-      yp -= lam * static_cast<double>(SideSign((flags >> 2) & 3));
-      if (MODE == 1) s.erec[i] = EndRec{tau, delta, (flags >> 2) & 3u};
-    }
-    a[k] = tau - yp;
-    dl[k] = delta;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const double aj = a[k] + (j == 0 ? -static_cast<double>(delta) : (j == 2 ? static_cast<double>(delta) : 0.0));
-      if (b & kHead) {
-        acc[j] = ClipMap{0.0, aj, aj};
-      } else {
+      for (int j = 0; j < 3; ++j) {
+        const double aj = j == 0 ? a0 - dk : (j == 2 ? a0 + dk : a0);
         acc[j].p += aj;
-        acc[j].lo = aj + fmin(fmax(acc[j].lo, -lam), lam);
-        acc[j].hi = aj + fmin(fmax(acc[j].hi, -lam), lam);
+        acc[j].lo = aj + fmin(fmax(acc[j].lo, -lek), lek);
+        acc[j].hi = aj + fmin(fmax(acc[j].hi, -lek), lek);
       }
     }
   }
   Clip3 acc3;
 #pragma unroll
   for (int j = 0; j < 3; ++j) acc3.m[j] = acc[j];
+  // (requested here, not at the top: 18 registers that would be live across the loop above)
+  Clip3 pre_part = Clip3Alg::identity();
+  if (MODE == 1) pre_part = TilePrefixLoad<Clip3Alg>(s.agg_clip, tile, s.direct);
   Clip3 total;
-  const Clip3 excl = BlockExclusive<Clip3Alg>(acc3, lds3, &total);
+  const Clip3 excl = BlockExclusive<Clip3Alg>(acc3, lds3, MODE == 0 ? &total : nullptr);
   if (MODE == 0) {
     if (t == 0) s.agg_clip[tile] = total;
     return;
@@ -545,55 +574,52 @@ __global__ __launch_bounds__(kBlock) void TvClipKernel(TvS<T> s) {
   double d[3];  // the value entering this chunk, per threshold
 #pragma unroll
   for (int j = 0; j < 3; ++j) d[j] = fmin(fmax(run.m[j].p, run.m[j].lo), run.m[j].hi);
-  unsigned o[4] = {0, 0, 0, 0};
+  unsigned o[kWords] = {};
   unsigned dec = Dec3Alg::identity();  // decode aggregate of the chunk: its LEFTMOST definite classes
+  unsigned finm = 0;
+  T xv[kItems];  // x of the samples whose region finished a level ago
+  {
+    Region g = region_of(rec_cur);
 #pragma unroll
-  for (int k = 0; k < kItems; ++k) {
-    const int64_t i = c0 + k;
-    const int b = ByteOf(w, k);
-    int nb8 = b;
-    unsigned f = 0x2Au;
-    if (i < s.n) {
-      if (!(actm & (1u << k))) {  // finished before, or finishing now
+    for (int k = 0; k < kItems; ++k) {
+      const unsigned b = static_cast<unsigned>(ByteOf(w, k));
+      double a0, dk, lek;
+      bool act, fnow;
+      sample(k, g, &a0, &dk, &lek, &act, &fnow);
+      if (act && (b & kEnd)) s.erec[c0 + k] = EndRec{g.tau, static_cast<float>(g.dd), g.crf};
+      xv[k] = static_cast<T>(g.tau);
+      finm |= (fnow ? 1u : 0u) << k;
+      unsigned f = 0u;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) d[j] = 0.0;
-        if (finm & (1u << k)) nb8 = (b & 3) | kDone;
-        f = 0u;
-      } else {
-        f = 0u;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double aj = a[k] + (j == 0 ? -static_cast<double>(dl[k]) : (j == 2 ? static_cast<double>(dl[k]) : 0.0));
-          d[j] = (b & kHead) ? aj : aj + fmin(fmax(d[j], -lam), lam);
-          unsigned cls;
-          if (b & kEnd) cls = d[j] < 0.0 ? 1u : 0u;  // region end: definite
-          else if (d[j] < -lam) cls = 1u;
-          else if (d[j] >= lam) cls = 0u;
-          else cls = 2u;
-          f |= cls << (2 * j);
-        }
-        nb8 = (b & 3) | static_cast<int>(f << 2);
+      for (int j = 0; j < 3; ++j) {
+        const double aj = j == 0 ? a0 - dk : (j == 2 ? a0 + dk : a0);
+        const double dj = aj + fmin(fmax(d[j], -lek), lek);
+        d[j] = dj;
+        // region end: definite (d < 0); elsewhere 1 below -lam, 0 from lam on, 2 (copy) in between
+        const unsigned below = dj < -lam ? 1u : 0u, above = dj >= lam ? 1u : 0u, neg = dj < 0.0 ? 1u : 0u;
+        const unsigned cls = (b & kEnd) ? neg : (below | ((1u - below) & (1u - above)) << 1);
+        f |= cls << (2 * j);
       }
+      const unsigned nb8 = act ? ((b & 3u) | (f << 2)) : (fnow ? ((b & 3u) | static_cast<unsigned>(kDone)) : b);
+      const unsigned fd = act ? f : (k < nvalid ? 0u : 0x2Au);  // finished samples decode as zeros
+      dec = Dec3Alg::combine(fd, dec);  // keeps what is already definite: the leftmost wins
+      o[k >> 2] |= nb8 << (8 * (k & 3));
     }
-    dec = Dec3Alg::combine(f, dec);  // keeps what is already definite: the leftmost wins
-    o[k >> 2] |= static_cast<unsigned>(nb8) << (8 * (k & 3));
   }
-  *reinterpret_cast<uint4*>(s.st + c0) = make_uint4(o[0], o[1], o[2], o[3]);
-  if (finm == 0xffffu && s.aligned && c0 + kItems <= s.n) {
+  StoreBytes(s.st + c0, o);
+  if (finm == kAllItems && s.aligned) {
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        reinterpret_cast<float4*>(s.x + c0)[q] =
-            make_float4(static_cast<float>(a[4 * q]), static_cast<float>(a[4 * q + 1]),
-                        static_cast<float>(a[4 * q + 2]), static_cast<float>(a[4 * q + 3]));
+      for (int q = 0; q < kItems / 4; ++q)
+        reinterpret_cast<float4*>(s.x + c0)[q] = make_float4(xv[4 * q], xv[4 * q + 1], xv[4 * q + 2], xv[4 * q + 3]);
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) reinterpret_cast<double2*>(s.x + c0)[q] = make_double2(a[2 * q], a[2 * q + 1]);
+      for (int q = 0; q < kItems / 2; ++q) reinterpret_cast<double2*>(s.x + c0)[q] = make_double2(xv[2 * q], xv[2 * q + 1]);
     }
   } else if (finm) {
 #pragma unroll
     for (int k = 0; k < kItems; ++k)
-      if (finm & (1u << k)) s.x[c0 + k] = static_cast<T>(a[k]);
+      if (finm & (1u << k)) s.x[c0 + k] = xv[k];
   }
   // tile aggregate of the backward decode scan: the fold from the tile's right end to its left
   // end keeps, per threshold, the leftmost definite class
@@ -627,9 +653,9 @@ __global__ __launch_bounds__(kBlock) void TvDecodeKernel(TvS<T> s) {
   }
   if (t == 0) s.tile_head[tile] = -1;  // the boundary pass of this level rebuilds it
   const int64_t c0 = (tile * kBlock + chunk) * kItems;
-  const uint4 bw = *reinterpret_cast<const uint4*>(s.st + c0);
+  unsigned w[kWords];
+  LoadBytes(s.st + c0, w);
   const unsigned pre_part = TilePrefixLoad<Dec3Alg>(s.dagg, pos, s.direct);
-  const unsigned w[4] = {bw.x, bw.y, bw.z, bw.w};
   unsigned acc = Dec3Alg::identity();
 #pragma unroll
   for (int k = kItems - 1; k >= 0; --k) {
@@ -647,7 +673,9 @@ __global__ __launch_bounds__(kBlock) void TvDecodeKernel(TvS<T> s) {
     return r & ~(und | (und << 1)) & 0x15u;
   };
   int lab_next = __popc(decoded(run));
-  unsigned o[4] = {bw.x, bw.y, bw.z, bw.w};
+  unsigned o[kWords];
+#pragma unroll
+  for (int q = 0; q < kWords; ++q) o[q] = w[q];
   int32_t fne = kInf, foe = kInf;
   int ncut = 0;
 #pragma unroll
@@ -673,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void TvDecodeKernel(TvS<T> s) {
     ncut += cut_r ? 1 : 0;
     lab_next = lab;
   }
-  *reinterpret_cast<uint4*>(s.st + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+  StoreBytes(s.st + c0, o);
   // tile aggregates of the boundary scan (a minimum: any order) and the cut count
   Int2 mn{fne, foe};
   const int lane = t & 63, wave = t >> 6;
@@ -710,14 +738,14 @@ __global__ __launch_bounds__(kBlock) void TvBoundKernel(TvS<T> s) {
   const int t = threadIdx.x, chunk = kBlock - 1 - t;
   if (s.tdone[tile]) return;
   const int64_t c0 = (tile * kBlock + chunk) * kItems;
-  const uint4 bw = *reinterpret_cast<const uint4*>(s.st + c0);
+  unsigned w[kWords];
+  LoadBytes(s.st + c0, w);
   const Int2 pre_part = TilePrefixLoad<MinAlg>(s.bagg, pos, s.direct);
-  const unsigned w[4] = {bw.x, bw.y, bw.z, bw.w};
   // The bytes left and right of the chunk sit in the neighbouring lanes' registers (the scan runs
   // backwards: the chunk before this one belongs to lane + 1, the one after it to lane - 1); only
   // the lanes at a wave's edge read them from memory.
   const int lane = t & 63;
-  const unsigned up = __shfl_down(bw.w, 1, 64), dn = __shfl_up(bw.x, 1, 64);
+  const unsigned up = __shfl_down(w[kWords - 1], 1, 64), dn = __shfl_up(w[0], 1, 64);
   int bl = static_cast<int>(up >> 24), br = static_cast<int>(dn & 0xff);
   if (lane == 63) bl = c0 > 0 ? s.st[c0 - 1] : 0;
   if (lane == 0) br = c0 + kItems < s.n ? s.st[c0 + kItems] : 0;
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(kBlock) void TvBoundKernel(TvS<T> s) {
   const Int2 excl = BlockExclusive<MinAlg>(acc, lds2, &tot);
   const Int2 pre = TilePrefixFinish<MinAlg>(pre_part, s.direct, lds2);
   Int2 run = MinAlg::combine(pre, excl);
-  unsigned o[4] = {0, 0, 0, 0};
+  unsigned o[kWords] = {};
 #pragma unroll
   for (int k = kItems - 1; k >= 0; --k) {
     const int64_t i = c0 + k;
@@ -794,7 +822,7 @@ __global__ __launch_bounds__(kBlock) void TvBoundKernel(TvS<T> s) {
       atomicMax(&s.tile_head[i / kTile], static_cast<int32_t>(i));
     }
   }
-  *reinterpret_cast<uint4*>(s.st2 + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+  StoreBytes(s.st2 + c0, o);
   // a tile whose samples are all finished drops out of every later pass
   const int wave = t >> 6;
   const bool wave_done = __all(all_done ? 1 : 0);
@@ -827,8 +855,8 @@ __global__ __launch_bounds__(kBlock) void TvFlushKernel(TvS<T> s) {
   const int t = threadIdx.x;
   if (s.tdone[tile]) return;
   const int64_t c0 = (tile * kBlock + t) * kItems;
-  const uint4 bw = *reinterpret_cast<const uint4*>(s.st + c0);
-  const unsigned w[4] = {bw.x, bw.y, bw.z, bw.w};
+  unsigned w[kWords];
+  LoadBytes(s.st + c0, w);
   int32_t last = -1;
 #pragma unroll
   for (int k = 0; k < kItems; ++k)
@@ -855,22 +883,29 @@ __global__ __launch_bounds__(kBlock) void TvFlushKernel(TvS<T> s) {
 }
 
 template <class T>
-__global__ void TvInitKernel(TvS<T> s) {
-  // one region [0, n-1] without neighbours; delta from the spread of 64 block means
-  s.st[0] = static_cast<uint8_t>(s.st[0] | kHead);
-  s.st[s.n - 1] = static_cast<uint8_t>(s.st[s.n - 1] | kEnd);
+__global__ __launch_bounds__(64) void TvInitKernel(TvS<T> s) {
+  // one region [0, n-1] without neighbours; delta from the spread of 64 block means (one lane each)
+  const int lane = threadIdx.x;
   const int64_t nblk = s.n < 64 ? s.n : 64;
-  double sum = 0.0, sq = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) {
-    const int64_t e0 = b * s.n / nblk, e1 = (b + 1) * s.n / nblk;
-    const double m = (s.Pp[e1] - s.Pp[e0]) / static_cast<double>(e1 > e0 ? e1 - e0 : 1);
-    sum += m;
-    sq += m * m;
+  double m = 0.0;
+  if (lane < nblk) {
+    const int64_t e0 = lane * s.n / nblk, e1 = (lane + 1) * s.n / nblk;
+    m = (s.Pp[e1] - s.Pp[e0]) / static_cast<double>(e1 > e0 ? e1 - e0 : 1);
   }
-  const double mean = sum / static_cast<double>(nblk);
-  const double var = fmax(sq / static_cast<double>(nblk) - mean * mean, 0.0);
-  s.hrec[0] = HeadRec{s.Pp[s.n] / static_cast<double>(s.n), static_cast<float>(0.67 * sqrt(var)), 0u};
-  s.tile_head[0] = 0;
+  double sum = m, sq = m * m;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+    sq += __shfl_down(sq, off, 64);
+  }
+  if (lane == 0) {
+    s.st[0] = static_cast<uint8_t>(s.st[0] | kHead);
+    s.st[s.n - 1] = static_cast<uint8_t>(s.st[s.n - 1] | kEnd);
+    const double mean = sum / static_cast<double>(nblk);
+    const double var = fmax(sq / static_cast<double>(nblk) - mean * mean, 0.0);
+    s.hrec[0] = HeadRec{s.Pp[s.n] / static_cast<double>(s.n), static_cast<float>(0.67 * sqrt(var)), 0u};
+    s.tile_head[0] = 0;
+  }
 }
 
 template <class T> int Tv1dLevelSets3(const DVec& xv, const DVec& yv, double lam) {
@@ -931,7 +966,7 @@ template <class T> int Tv1dLevelSets3(const DVec& xv, const DVec& yv, double lam
   EPS_HIP(hipMemsetAsync(s.cuts, 0, static_cast<size_t>(kMaxLevels) * sizeof(unsigned long long), q));
   s.st = stA;
   s.st2 = stB;
-  hipLaunchKernelGGL(TvInitKernel<T>, dim3(1), dim3(1), 0, q, s);
+  hipLaunchKernelGGL(TvInitKernel<T>, dim3(1), dim3(64), 0, q, s);
 
   const dim3 grid(static_cast<unsigned>(nb)), block(kBlock);
   auto enqueue_level = [&](int level) {
@@ -957,7 +992,7 @@ template <class T> int Tv1dLevelSets3(const DVec& xv, const DVec& yv, double lam
   int enq = 0, last = -1;
   std::vector<unsigned long long> h(kMaxLevels);
   while (last < 0) {
-    const int batch = enq == 0 ? 5 : 2;
+    const int batch = enq == 0 ? 6 : 2;
     EPS_CHECK_MSG(enq + batch < kMaxLevels, "tv1d: level-set recursion did not terminate");
     const int first = enq;
     for (int b = 0; b < batch; ++b) enqueue_level(enq++);

@@ -20,7 +20,7 @@ def side_sign(code):
     return 1 if code == 1 else (-1 if code == 2 else 0)
 
 
-def tv1d_levelsets3(y, lam, max_levels=10000, stats=None, kappa=0.5, root=0.67):
+def tv1d_levelsets3(y, lam, max_levels=10000, stats=None, kappa=0.5, root=0.67, mode='parent', nblk=16, bfac=0.67):
     y = np.asarray(y, dtype=np.float64)
     n = y.size
     if n == 1 or lam == 0:
@@ -155,6 +155,13 @@ def tv1d_levelsets3(y, lam, max_levels=10000, stats=None, kappa=0.5, root=0.67):
             else:
                 d_new = kappa * min(t_new - t2, t3 - t_new)
             d_new = max(d_new, 0.0)
+            if mode != 'parent':
+                L = r - i + 1
+                nbk = min(nblk, L)
+                ed = i + (np.arange(nbk + 1) * L) // nbk
+                bm = (Pp[ed[1:]] - Pp[ed[:-1]]) / np.maximum(1, ed[1:] - ed[:-1])
+                d_blk = bfac * bm.std()
+                d_new = d_blk if mode == 'blocks' else min(d_new, d_blk) if mode == 'min' else max(d_new, d_blk)
             fin = bool(b & HEAD) and r == eo
             h_tau[i], h_del[i] = t_new, np.float32(d_new)
             h_flags[i] = clc | (crc << 2) | (16 if fin else 0)
