@@ -319,7 +319,9 @@ class ProxADMMSolver final : public Solver {
     if (ShardSpec::Get().active() && ShardSpec::Get().consensus_terms()) return;
     FusedState f;
     if (!prox_[0]->DescribeLeastSquares(&f.ls) || !prox_[1]->DescribeScaledZone(&f.sz)) return;
-    if ((f.sz.alpha_vec.n > 0 || f.sz.beta_vec.n > 0) && data_->dtype() != F32) return;
+    if ((f.sz.alpha_vec.n > 0 && f.sz.alpha_vec.dt != data_->dtype()) ||
+        (f.sz.beta_vec.n > 0 && f.sz.beta_vec.dt != data_->dtype()))
+      return;
     const std::string ck = affine::constraint_key(0);
     if (f.ls.constraint_key != ck || f.sz.constraint_key != ck) return;
     if (A_.data().size() != 2 || !A_.has_key(ck, f.ls.var_key) || !A_.has_key(ck, f.sz.var_key))
@@ -802,12 +804,12 @@ class ProxADMMTwoBlockSolver final : public Solver {
   // [SUM_SQUARE with a dense argument map, scaled-zone prox], one constraint a0 x0 + a1 x1 = 0
   // without a constant: the x-updates are the same two operators as in the multi-block driver, the
   // z-update is the closed-form projection onto the constraint, so one pass over the data matrix
-  // does a whole sweep (kernels_fused.hip, chain 1).  f32, single GPU.
+  // does a whole sweep (kernels_fused.hip, chain 1).  f32 and f64, single GPU.
   void TryEnableFused() {
     fused_ = false;
     const char* env = std::getenv("EPSILON_HIP_FUSED");
     if (env && env[0] == '0') return;
-    if (data_->dtype() != F32 || N_ != 2 || problem_.constraint.size() != 1) return;
+    if (N_ != 2 || problem_.constraint.size() != 1) return;
     if (ShardSpec::Get().active()) return;
     if (!constr_H_.b.data().empty()) return;
     FusedState f;
@@ -831,7 +833,9 @@ class ProxADMMTwoBlockSolver final : public Solver {
     if (f.ls.rhs_arg.n != 0 && f.ls.rhs_arg.n != f.m) return;
     const DenseMatrixImpl& D = *f.ls.Dinv_arg;
     if (D.trans() || D.rows() != f.m) return;
-    const DType dt = F32;
+    const DType dt = data_->dtype();
+    if ((f.sz.alpha_vec.n > 0 && f.sz.alpha_vec.dt != dt) || (f.sz.beta_vec.n > 0 && f.sz.beta_vec.dt != dt)) return;
+    if (L.dtype() != dt || D.dtype() != dt) return;
     auto state = [&](const BlockVector& src, const std::string& key) {
       DVec v = DVec::Zeros(f.n, dt);
       if (src.has_key(key)) k::Copy(v, src(key));

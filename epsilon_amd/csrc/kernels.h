@@ -200,6 +200,10 @@ int JacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps
 // from 1536 columns up (measured crossover on MI355X; EPSILON_HIP_SVD=block|scalar forces one).
 int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps = 40,
                    bool warm = false, bool row_sharded = false);
+// The same with the rotations applied to W only (no right factor is accumulated: a step moves
+// 0.6 of the bytes); fp32 block form.  JacobiSvdCanSkipV says whether it applies.
+bool JacobiSvdCanSkipV(int64_t m, int64_t n, DType dt);
+int JacobiSvdNoV(const DVec& W, int64_t m, int64_t n, int max_sweeps = 40);
 void ColNorms(const DVec& W, int64_t m, int64_t n, const DVec& sigma, bool row_sharded = false);
 // W[:, j] *= xt[j] / sigma[j]   (0 where sigma[j] == 0, as ortho_invariant.cc:44-49)
 void ColScaleByRatio(const DVec& W, int64_t m, int64_t n, const DVec& sigma, const DVec& xt);

@@ -72,6 +72,9 @@ __device__ inline float ChainTwoBlock(float d, const FusedScalars& c, float z0p,
 // arithmetic type, linear/linear_map.h:35) ---------------------------------------------------------
 template <class T> struct FusedScalarsT {
   T kappa, Bs, Cs, a1, lam, alpha, beta, M;
+  T a0, inv_aa;        // two-block form: constraint a0 x0 + a1 x1 = 0, 1 / (a0^2 + a1^2)
+  const T* alpha_v;    // per-column alpha / beta of the scaled zone (nullptr: the uniform values)
+  const T* beta_v;
 };
 
 template <class T> __device__ inline T WaveSumT(T v) {
@@ -111,12 +114,37 @@ __device__ inline T ChainOneT(T d, const FusedScalarsT<T>& c, T u, T y0p, T y1p,
   return ((u3 - y0) - y1) + y0;
 }
 
+// The two-block driver's column (see ChainTwoBlock below for the line-by-line correspondence).
+template <class T>
+__device__ inline T ChainTwoBlockT(T d, const FusedScalarsT<T>& c, T z0p, T z1p, T u0p, T u1p, T* x0o,
+                                   T* x1o, T* z0o, T* z1o, T* u0o, T* u1o) {
+  const T v0 = z0p - u0p;
+  const T v1 = z1p - u1p;
+  const T x0 = c.kappa * d + v0;
+  const T x1 = c.Cs * ScaledZoneOneT<T>(c.Bs * v1, c.lam, c.alpha, c.beta, c.M);
+  const T w0 = x0 + u0p;
+  const T w1 = x1 + u1p;
+  const T t = (c.a0 * w0 + c.a1 * w1) * c.inv_aa;
+  const T z0 = w0 - c.a0 * t;
+  const T z1 = w1 - c.a1 * t;
+  const T u0 = u0p + (x0 - z0);
+  const T u1 = u1p + (x1 - z1);
+  *x0o = x0;
+  *x1o = x1;
+  *z0o = z0;
+  *z1o = z1;
+  *u0o = u0;
+  *u1o = u1;
+  return z0 - u0;
+}
+
 // f64 pass: 16-byte loads hold two rows, so 512 threads x 10 chunks own up to 10240 rows.
-template <int NR, int BS>
+// MODE 0 / 1 as in the f32 kernel below: the multi-block driver's chain, the two-block driver's.
+template <int NR, int BS, int MODE>
 __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernelF64(
     int64_t m, int64_t n, const double* __restrict__ A, int64_t lda, const double* __restrict__ w,
     FusedScalarsT<double> c, double* u, double* x0, double* x1, double* y0, double* y1,
-    double* y1prev, double* __restrict__ tpart) {
+    double* y1prev, double* __restrict__ tpart, double* e0, double* e1) {
   __shared__ double red[2][BS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double2 wv[NR], tp[NR];
@@ -157,6 +185,8 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernelF64(
     const int64_t step_n = (jn >= 0 && column(step + 1) < 0) ? step + 2 : step + 1;
     if (jn >= 0) load(nxt, jn);
     const double uj = u[j], y0j = y0[j], y1j = y1[j];
+    double u1j = 0.0;
+    if (MODE == 1) u1j = e0[j];
     double d = 0.0;
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
@@ -170,15 +200,34 @@ __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernelF64(
 #pragma unroll
     for (int w2 = 1; w2 < BS / 64; ++w2) d += red[par][w2];
     par ^= 1;
-    double nx0, nx1, ny0, ny1, nu;
-    const double v0n = ChainOneT<double>(d, c, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
-    if (tid == 0) {
-      y1prev[j] = y1j;
-      x0[j] = nx0;
-      x1[j] = nx1;
-      y0[j] = ny0;
-      y1[j] = ny1;
-      u[j] = nu;
+    FusedScalarsT<double> cj = c;
+    if (c.alpha_v != nullptr) cj.alpha = c.alpha_v[j];
+    if (c.beta_v != nullptr) cj.beta = c.beta_v[j];
+    double v0n;
+    if (MODE == 0) {
+      double nx0, nx1, ny0, ny1, nu;
+      v0n = ChainOneT<double>(d, cj, uj, y0j, y1j, &nx0, &nx1, &ny0, &ny1, &nu);
+      if (tid == 0) {
+        y1prev[j] = y1j;
+        x0[j] = nx0;
+        x1[j] = nx1;
+        y0[j] = ny0;
+        y1[j] = ny1;
+        u[j] = nu;
+      }
+    } else {
+      double nx0, nx1, nz0, nz1, nu0, nu1;
+      v0n = ChainTwoBlockT<double>(d, cj, y0j, y1j, uj, u1j, &nx0, &nx1, &nz0, &nz1, &nu0, &nu1);
+      if (tid == 0) {
+        y1prev[j] = y0j;  // z_prev
+        e1[j] = y1j;
+        x0[j] = nx0;
+        x1[j] = nx1;
+        y0[j] = nz0;
+        y1[j] = nz1;
+        u[j] = nu0;
+        e0[j] = nu1;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
@@ -636,16 +685,36 @@ int LassoFusedGrid(int64_t m, int64_t n, DType dt) {
 
 namespace {
 void LassoFusedPassF64(const LassoFusedArgs& a, int grid, int block) {
-  FusedScalarsT<double> c{a.kappa, a.Bs, a.Cs, a.a1, a.lam, a.sz_alpha, a.sz_beta, a.sz_M};
+  FusedScalarsT<double> c{a.kappa, a.Bs, a.Cs, a.a1, a.lam, a.sz_alpha, a.sz_beta, a.sz_M,
+                          a.a0, 1.0 / (a.a0 * a.a0 + a.a1 * a.a1), nullptr, nullptr};
   EPS_CHECK_MSG(a.epoch == nullptr, "the peer exchange is f32 only");
+  if (a.sz_alpha_vec.n > 0) {
+    EPS_CHECK(a.sz_alpha_vec.n == a.n && a.sz_alpha_vec.dt == F64);
+    c.alpha_v = a.sz_alpha_vec.as<double>();
+  }
+  if (a.sz_beta_vec.n > 0) {
+    EPS_CHECK(a.sz_beta_vec.n == a.n && a.sz_beta_vec.dt == F64);
+    c.beta_v = a.sz_beta_vec.as<double>();
+  }
+  if (a.chain == 1) EPS_CHECK(a.e0.n == a.n && a.e1.n == a.n && a.e0.dt == F64 && a.e1.dt == F64);
+  double* e0 = a.chain == 1 ? a.e0.as<double>() : nullptr;
+  double* e1 = a.chain == 1 ? a.e1.as<double>() : nullptr;
   ProfScope prof("lasso_fused", a.m, a.n);
   const int64_t need = (a.m + 2 * block - 1) / (2 * block);  // double2 row chunks per thread
   hipStream_t s = Runtime::Get().stream();
-#define EPS_FUSED_CASE64(NRV, BSV)                                                                     \
-  hipLaunchKernelGGL((LassoFusedStreamKernelF64<NRV, BSV>), dim3(grid), dim3(BSV), 0, s, a.m, a.n,      \
-                     a.A.as<double>(), a.lda, a.w.as<double>(), c, a.u.as<double>(), a.x0.as<double>(), \
-                     a.x1.as<double>(), a.y0.as<double>(), a.y1.as<double>(), a.y1prev.as<double>(),    \
-                     a.tpart.as<double>())
+#define EPS_FUSED_CASE64(NRV, BSV)                                                                        \
+  do {                                                                                                    \
+    if (a.chain == 1)                                                                                     \
+      hipLaunchKernelGGL((LassoFusedStreamKernelF64<NRV, BSV, 1>), dim3(grid), dim3(BSV), 0, s, a.m, a.n, \
+                         a.A.as<double>(), a.lda, a.w.as<double>(), c, a.u.as<double>(),                  \
+                         a.x0.as<double>(), a.x1.as<double>(), a.y0.as<double>(), a.y1.as<double>(),      \
+                         a.y1prev.as<double>(), a.tpart.as<double>(), e0, e1);                            \
+    else                                                                                                  \
+      hipLaunchKernelGGL((LassoFusedStreamKernelF64<NRV, BSV, 0>), dim3(grid), dim3(BSV), 0, s, a.m, a.n, \
+                         a.A.as<double>(), a.lda, a.w.as<double>(), c, a.u.as<double>(),                  \
+                         a.x0.as<double>(), a.x1.as<double>(), a.y0.as<double>(), a.y1.as<double>(),      \
+                         a.y1prev.as<double>(), a.tpart.as<double>(), e0, e1);                            \
+  } while (0)
   if (block == 256) {
     if (need <= 1) EPS_FUSED_CASE64(1, 256);
     else if (need <= 2) EPS_FUSED_CASE64(2, 256);
@@ -671,8 +740,6 @@ void LassoFusedPass(const LassoFusedArgs& a) {
   const int block = LassoFusedBlock(a.m, a.n, dt);
   EPS_CHECK(a.tpart.n >= static_cast<int64_t>(grid) * a.m && a.tpart.dt == dt);
   if (dt == F64) {
-    EPS_CHECK_MSG(a.chain == 0, "the two-block chain is f32 only");
-    EPS_CHECK_MSG(a.sz_alpha_vec.n == 0 && a.sz_beta_vec.n == 0, "per-column alpha / beta: f32 pass only");
     LassoFusedPassF64(a, grid, block);
     return;
   }

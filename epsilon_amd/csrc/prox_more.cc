@@ -301,6 +301,8 @@ class OrthoInvariantProx : public VectorProx {
     dtype_ = arg.data_map()->dtype();
     eigen_prox_.reset();
     V_prev_ = DVec();
+    basis_prev_ = DVec();
+    basis_is_left_ = false;
     calls_ = 0;
     const char* e = std::getenv("EPSILON_HIP_SVD_WARM");
     warm_start_ = !(e && e[0] == '0');
@@ -349,6 +351,10 @@ class OrthoInvariantProx : public VectorProx {
         if (const char* e = std::getenv("EPSILON_HIP_SVD_PARTIAL_BACKOFF")) partial_backoff_ = std::atoi(e);
         ++partial_fail_streak_;
       }
+    }
+    if (!symmetric_part_ && !row_sharded && m_ >= n_ && k::JacobiSvdCanSkipV(m_, n_, y.dt)) {
+      ApplyOneSided(input, output, y);
+      return;
     }
     DVec W, R;
     double shift = 0;
@@ -448,6 +454,98 @@ class OrthoInvariantProx : public VectorProx {
   }
 
  private:
+  // The decomposition WITHOUT an accumulated factor (fp32 block Jacobi on the matrix cores, m >= n).
+  // X = U diag(x~) V^T needs only ONE orthonormal side: with Q the normalised columns of the
+  // converged W (left vectors when W = Y V0, right vectors when W = Y^T U0) and Z the other side
+  // re-formed from Y (Z = Y^T Q or Y Q, columns sigma_i v_i / sigma_i u_i),
+  //     X = Q diag(x~ / sigma) Z^T      resp.     X = Z diag(x~ / sigma) Q^T .
+  // So the Jacobi sweeps rotate W alone - a step streams 1.2 GB instead of 2.0 GB at n = 1e4 - and
+  // the basis Q of one application is the orthogonal start of the next one, applied from the
+  // OTHER side (W = Y^T Q_left, then W = Y Q_right, ...): warm starts survive although no factor
+  // is ever accumulated.  Q's columns are orthonormal to the accuracy of the sweeps whatever the
+  // singular value (a column of noise is still a unit vector orthogonal to the others), one
+  // Newton-Schulz step squares the defect, and sigma comes from the re-formed Z - the same clean-up
+  // the two-sided path applies to V and W.  (reference prox/ortho_invariant.cc:36-66 forms all
+  // three factors from eig(Y^T Y).)
+  void ApplyOneSided(const VectorProxInput& input, VectorProxOutput* output, const DVec& y) {
+    const int64_t m = m_, n = n_;
+    const DType dt = y.dt;
+    const bool have = warm_start_ && basis_prev_.dt == dt && (calls_ % 64) != 0 &&
+                      basis_prev_.n == (basis_is_left_ ? m * n : n * n);
+    ++calls_;
+    // left == true: this application starts from left vectors (W = Y^T U0, n x n) and produces Q = V
+    const bool left = have && basis_is_left_;
+    const int64_t wr = left ? n : m;  // rows of W
+    DVec W;
+    if (!have) {
+      W = y.Clone();
+    } else if (left) {
+      W = DVec::Empty(n * n, dt);
+      k::Gemm(true, false, n, n, m, 1.0, y, m, basis_prev_, m, 0.0, W, n);
+    } else {
+      W = DVec::Empty(m * n, dt);
+      k::Gemm(false, false, m, n, n, 1.0, y, m, basis_prev_, n, 0.0, W, m);
+    }
+    basis_prev_ = DVec();
+    k::JacobiSvdNoV(W, wr, n, 40);
+    DVec one = DVec::Full(n, 1.0, dt), s0 = DVec::Empty(n, dt);
+    k::ColNorms(W, wr, n, s0, false);
+    k::ColScaleByRatio(W, wr, n, s0, one);  // Q0 = W diag(1 / sigma) (a zero column stays zero)
+    // Newton-Schulz: Q = Q0 (3 I - Q0^T Q0) / 2
+    DVec T = DVec::Empty(n * n, dt);
+    k::Gemm(true, false, n, n, wr, -1.0, W, wr, W, wr, 0.0, T, n);
+    k::AddDiag(T, n, n, 3.0, nullptr);
+    DVec Q = DVec::Empty(wr * n, dt);
+    k::Gemm(false, false, wr, n, n, 0.5, W, wr, T, n, 0.0, Q, wr);
+    W = DVec();
+    // the other side, re-formed from Y: Z = Y Q (m x n) or Y^T Q (n x n); columns of length sigma_i
+    const int64_t zr = left ? m : n;
+    DVec Z = left ? DVec::Empty(m * n, dt) : T;
+    if (left) k::Gemm(false, false, m, n, n, 1.0, y, m, Q, n, 0.0, Z, m);
+    else k::Gemm(true, false, n, n, m, 1.0, y, m, Q, m, 0.0, Z, n);
+    DVec sigma = DVec::Empty(n, dt);
+    k::ColNorms(Z, zr, n, sigma, false);
+    // nested prox on the singular values (ortho_invariant.cc:100-116)
+    BlockVector in;
+    DVec xt, t;
+    LocalShardScope replicated_scope{std::set<std::string>()};
+    if (epigraph_) {
+      in.Set(affine::arg_key(0), sigma);
+      in.Set(affine::arg_key(1), input.value_vec(1));
+      BlockVector out = eigen_prox_->Apply(in);
+      xt = out(affine::arg_key(0));
+      t = out(affine::arg_key(1));
+    } else {
+      DVec scaled = DVec::Empty(n, dt);
+      k::Axpby(scaled, alpha_, sigma, 0.0);
+      in.Set(affine::arg_key(0), scaled);
+      xt = eigen_prox_->Apply(in)(affine::arg_key(0));
+    }
+    // keep Q for the next application (before it is scaled); a rank-deficient argument (a zero
+    // column) leaves no orthogonal basis: the next application starts cold
+    {
+      Runtime& rt = Runtime::Get();
+      std::vector<double> sh = s0.ToHost();
+      double smin = sh.empty() ? 0.0 : sh[0];
+      for (double v : sh) smin = std::min(smin, v);
+      (void)rt;
+      if (smin > 0.0 && warm_start_) {
+        basis_prev_ = Q.Clone();
+        basis_is_left_ = !left;  // Q holds left vectors when this application started from the right
+      }
+    }
+    DVec X = DVec::Empty(m * n, dt);
+    if (left) {  // X = Z diag(x~ / sigma) Q^T
+      k::ColScaleByRatio(Z, m, n, sigma, xt);
+      k::Gemm(false, true, m, n, n, 1.0, Z, m, Q, n, 0.0, X, m);
+    } else {     // X = Q diag(x~ / sigma) Z^T
+      k::ColScaleByRatio(Q, m, n, sigma, xt);
+      k::Gemm(false, true, m, n, n, 1.0, Q, m, Z, n, 0.0, X, m);
+    }
+    output->set_value(0, X);
+    if (epigraph_) output->set_value(1, t);
+  }
+
   // Columns of Q (rows x k) <- an orthonormal basis of their span (one-sided Jacobi on the k
   // columns: Q = W V^T, the columns of W orthogonal; a numerically null column becomes zero).
   static void Orthonormalise(const DVec& Q, int64_t rows, int64_t k) {
@@ -631,6 +729,10 @@ class OrthoInvariantProx : public VectorProx {
   std::unique_ptr<DataMap> eigen_data_;
   std::unique_ptr<ProxOperator> eigen_prox_;
   DVec V_prev_;  // right singular vectors of the previous application (warm start)
+  // one-sided form (fp32 block Jacobi without an accumulated factor, ApplyOneSided): the orthonormal
+  // basis the previous application produced - right vectors (n x n) or left vectors (m x n)
+  DVec basis_prev_;
+  bool basis_is_left_ = false;
   int64_t calls_ = 0;
   bool warm_start_ = true;
   // thresholded partial SVD (nuclear-norm prox of a large matrix)

@@ -193,6 +193,57 @@ def test_nuclear_norm_prox_full_size(solve_mod):
     torch.cuda.empty_cache()
 
 
+def test_nuclear_norm_prox_full_size_full_rank(solve_mod):
+    """The same operator on the matrix the reference's robust-PCA generator produces
+    (python/epopt/problems/robust_pca.py:5-22: rank-10 part + 10 % sparse part of 10 * randn) at
+    10^4 x 10^4 with lam = 1: 99.8 % of the singular values exceed the threshold, so the thresholded
+    partial route gives up and the FULL decomposition runs (the planted-rank test above never
+    reaches it at this size).  Certificate: P = (Y - X) / lam has ||P||_2 <= 1 and <X, P> = ||X||_*
+    (the nuclear norm of the full-rank X from torch's singular values on the device)."""
+    from epsilon_amd.wire import ProxFunction
+    n, r, lam = 10 ** 4, 10, 1.0
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    Y = (torch.randn(n, r, generator=g, device=dev, dtype=torch.float32) @
+         torch.randn(r, n, generator=g, device=dev, dtype=torch.float32))
+    mask = torch.rand(n, n, generator=g, device=dev) < 0.1
+    Y += mask * (10.0 * torch.randn(n, n, generator=g, device=dev, dtype=torch.float32))
+    del mask
+    Y = Y.double()
+    solve_mod.set_option("dtype", "f32")
+    Xv = ir.variable(n, n, "var:X")
+    expr = ir.prox(ProxFunction.NORM_NUCLEAR, Xv)
+    yb = Y.t().contiguous().cpu().numpy().tobytes()  # column-major bytes of Y
+    solve_mod.profile_reset()
+    solve_mod.profile_enable(True)
+    got = solve_mod.eval_prox(expr.proto.SerializeToString(), lam, expr.data, {"var:X": yb})
+    tags = solve_mod.profile_dump()
+    solve_mod.profile_enable(False)
+    del yb
+    assert any(t.startswith("block_jacobi_svd") for t in tags), sorted(tags)  # the full decomposition ran
+    X = torch.from_numpy(np.frombuffer(got["var:X"]).reshape(n, n).copy()).to(dev).t()
+    del got
+    P = (Y - X) / lam
+    v = torch.randn(n, 1, generator=g, device=dev, dtype=torch.float64)
+    for _ in range(60):
+        v = P.t() @ (P @ v)
+        v /= v.norm()
+    sigma_max = float((P @ v).norm())
+    # fp32 decomposition of a matrix with ||Y||_2 ~ 3e4: singular directions are resolved to
+    # ~1e-4 relative, i.e. ~1e-2 of lam in the worst direction of P
+    assert sigma_max <= 1.0 + 2e-2, sigma_max
+    inner = float((X * P).sum())
+    nuc = float(torch.linalg.svdvals(X.float()).double().sum())
+    assert abs(inner - nuc) <= 2e-3 * nuc, (inner, nuc)
+    # and the singular values themselves: sigma(X) = (sigma(Y) - lam)_+
+    sy = torch.linalg.svdvals(Y.float()).double()
+    want = float(torch.clamp(sy - lam, min=0).sum())
+    assert abs(nuc - want) <= 1e-3 * want, (nuc, want)
+    del X, Y, P
+    torch.cuda.empty_cache()
+
+
 def test_multiclass_hinge_full_size(solve_mod):
     """configs[3] at its full size (X 60000 x 784, k = 10, lam = 1; reference
     docs/notebooks/mnist.rst:88-129) on a learnable synthetic instance - labels planted by a random

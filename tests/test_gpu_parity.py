@@ -874,6 +874,60 @@ def test_fused_sweep_fp64(solve_mod, shape):
         np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-8, atol=1e-10, err_msg=k)
 
 
+@pytest.mark.parametrize("solver_id", [0, 1])
+@pytest.mark.parametrize("kind", ["lasso", "quantile"])
+@pytest.mark.parametrize("shape", [(200, 500), (700, 1501), (5200, 5301)])
+def test_fused_sweep_fp64_two_block_and_quantile(solve_mod, shape, kind, solver_id):
+    """Round 3: the fp64 fused pass also carries the TWO_BLOCK driver's chain
+    (prox_admm_two_block.cc:96-133) and per-column alpha / beta of the scaled zone (SUM_QUANTILE with
+    data vectors, scaled_zone.cc:34-76) - until now fp64 fell back to the operator path for both.
+    Fused against unfused against the oracle, to fp64 rounding."""
+    m, n = shape
+    if kind == "lasso":
+        if solver_id == 0:
+            pytest.skip("covered by test_fused_sweep_fp64")
+        prob, info = problems.lasso(m, n, seed=8)
+    else:
+        A, b = problems.regression_data(m, n, seed=8)
+        lam = 0.3 * np.abs(A.T.dot(b)).max()
+        x = ir.variable(n, 1, problems.LASSO_COPY)
+        y = ir.variable(n, 1, problems.LASSO_VAR)
+        f0 = ir.prox(ProxFunction.SUM_SQUARE, ir.add(ir.linear_map(ir.dense_matrix(A), x),
+                                                     ir.linear_map(ir.scalar(-1, m), ir.constant(b))))
+        rq = np.random.RandomState(9)
+        qa, qb = ir.constant(0.2 + rq.rand(n)), ir.constant(0.2 + rq.rand(n))
+        qd = dict(qa.data)
+        qd.update(qb.data)
+        f1 = ir.prox(ProxFunction.SUM_QUANTILE, y, alpha=lam, data=qd,
+                     scaled_zone_params=wire.ProxScaledZoneParams(alpha_expr=qa.proto, beta_expr=qb.proto))
+        prob = ir.Problem([f0, f1], [ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, n), y)))])
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    sb = wire.SolverParams(max_iterations=200, solver=solver_id).SerializeToString()
+    solve_mod.set_option("dtype", "f64")
+    try:
+        solve_mod.set_option("fused", "1")
+        solve_mod.profile_reset()
+        solve_mod.profile_enable(True)
+        st_f, x_f = solve_mod.solve(pb, [], sb, data)
+        tags = solve_mod.profile_dump()
+        solve_mod.profile_enable(False)
+        solve_mod.set_option("fused", "0")
+        st_g, x_g = solve_mod.solve(pb, [], sb, data)
+    finally:
+        solve_mod.set_option("fused", "1")
+        solve_mod.set_option("dtype", "f32")
+    assert any(t.startswith("lasso_fused:%dx%d" % (m, n)) for t in tags), sorted(tags)
+    st_o, x_o = orc.solve(pb, [], sb, data)
+    sf, sg, so = (wire.SolverStatus.FromString(s) for s in (st_f, st_g, st_o))
+    assert sf.state == sg.state == so.state
+    assert sf.num_iterations == sg.num_iterations == so.num_iterations
+    for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
+        np.testing.assert_allclose(getattr(sf.residuals, f), getattr(so.residuals, f), rtol=1e-8, atol=1e-11)
+    for k in x_o:
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_g[k]), rtol=1e-9, atol=1e-11, err_msg=k)
+        np.testing.assert_allclose(np.frombuffer(x_f[k]), np.frombuffer(x_o[k]), rtol=1e-8, atol=1e-10, err_msg=k)
+
+
 @pytest.mark.parametrize("apply_mode", ["slab", "replicated"])
 def test_fused_sweep_sharded(solve_mod, tmp_path, apply_mode):
     """Fused pass on column slabs with the all-reduce between the pass and the cached-inverse

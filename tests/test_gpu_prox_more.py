@@ -492,7 +492,8 @@ def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
     # the partial route was entered in every case; the full decomposition ran only where it had to
     names = list(tags)
     assert any(t.startswith("partial_svd") for t in names), names
-    full = ("block_jacobi_svd:%dx%d" % (m, n)) in names or ("jacobi_svd:%dx%d" % (m, n)) in names
+    full = any(t in names for t in ("block_jacobi_svd:%dx%d" % (m, n), "jacobi_svd:%dx%d" % (m, n),
+                                    "block_jacobi_svd_no_v:%dx%d" % (m, n)))  # (fp32, m >= n: the one-sided form)
     if case != "edge_just_above":  # (either route is fine there, the result is what counts)
         assert full == (case in ("full_rank", "edge_at_threshold")), (case, names)
 

@@ -48,7 +48,7 @@ def main():
             tags = _solve.profile_dump()
             _solve.profile_enable(False)
             part = sum(ms for t, (c, ms) in tags.items() if t.startswith("partial_svd"))
-            full = sum(ms for t, (c, ms) in tags.items() if t == "block_jacobi_svd:%dx%d" % (n, n))
+            full = sum(ms for t, (c, ms) in tags.items() if t.startswith("block_jacobi_svd") and t.endswith(":%dx%d" % (n, n)))
             print(json.dumps({"case": case, "n": n, "lam": lam, "rep": rep, "eval_prox_s_incl_host_copies": round(dt, 4),
                               "partial_svd_ms": round(part, 2), "full_jacobi_ms": round(full, 2)}), flush=True)
             del got

@@ -33,6 +33,8 @@ if os.path.exists(db):
     print("n=$n last prox: span %.3f ms busy %.3f ms, %d kernels" % ((half[-1][2]-half[0][1])/1e6, sum(v[1] for v in agg.values())/1e3, len(half)))
     for n_, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:9]:
         print("  %-40s x%-3d %8.1f us  (%.1f us each)" % (n_, c, t, t / c))
+    for key in ("TvClipKernel<float, 1>", "TvClipKernel<float, 0>", "TvBoundKernel<float>", "TvDecodeKernel<float>"):
+        print("  per level %-24s" % key, " ".join("%.0f" % ((e - s) / 1e3) for n_, s, e in half if n_ == key))
 PY
 rm -rf $O/prof_tvx
 done
