@@ -262,6 +262,10 @@ def main():
     from epsilon_amd import _solve, wire
 
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if args.comm == "rccl" and world > torch.cuda.device_count():
+        sys.exit("bench.py: %d ranks but %d visible GPU(s): one rank per GPU over RCCL needs %d devices "
+                 "(--comm host rehearses the N > 1 path with ranks sharing the devices)"
+                 % (world, torch.cuda.device_count(), world))
     if args.comm == "host":
         local_rank = local_rank % torch.cuda.device_count()
         os.environ["EPSILON_HIP_DEVICE"] = str(local_rank)
