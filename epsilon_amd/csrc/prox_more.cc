@@ -303,6 +303,10 @@ class OrthoInvariantProx : public VectorProx {
     V_prev_ = DVec();
     basis_prev_ = DVec();
     basis_is_left_ = false;
+    {
+      const char* pe2 = std::getenv("EPSILON_HIP_SVD_POLAR");
+      polar_enabled_ = !(pe2 && pe2[0] == '0');
+    }
     calls_ = 0;
     const char* e = std::getenv("EPSILON_HIP_SVD_WARM");
     warm_start_ = !(e && e[0] == '0');
@@ -351,6 +355,23 @@ class OrthoInvariantProx : public VectorProx {
         if (const char* e = std::getenv("EPSILON_HIP_SVD_PARTIAL_BACKOFF")) partial_backoff_ = std::atoi(e);
         ++partial_fail_streak_;
       }
+    }
+    // Full rank above the threshold: the GEMM-only polar route while no warm basis exists.  At
+    // n = 1e4 a polar application costs 0.65 s, a cold Jacobi one 1.6 s, a warm-started one 0.25 s:
+    // a run that stops after one application (the reference's robust-PCA benchmark at its default
+    // tolerance) should never pay for the decomposition, a long run should reach the warm starts.
+    // Ski-rental rule: stay on the polar route until its extra cost over warm starts (0.4 s per
+    // application) has reached the price of the cold decomposition - kPolarCalls = 4 applications.
+    if (eigen_prox_type_ == pb::ProxFunction::NORM_1 && !symmetric_part_ && !epigraph_ && !row_sharded &&
+        polar_enabled_ && m_ >= n_ && n_ >= kPolarMinSize && basis_prev_.n == 0 && V_prev_.n == 0 &&
+        calls_ < kPolarCalls) {
+      DVec X;
+      if (PolarNuclearProx(y, input.lambda(), &X)) {
+        ++calls_;
+        output->set_value(0, X);
+        return;
+      }
+      polar_enabled_ = false;  // rejected once: this operator stays on the decomposition
     }
     if (!symmetric_part_ && !row_sharded && m_ >= n_ && k::JacobiSvdCanSkipV(m_, n_, y.dt)) {
       ApplyOneSided(input, output, y);
@@ -546,6 +567,283 @@ class OrthoInvariantProx : public VectorProx {
     if (epigraph_) output->set_value(1, t);
   }
 
+  // ---- nuclear-norm prox WITHOUT a decomposition: GEMMs only (round 3) ---------------------------
+  // With the polar decomposition Y = Q H (Q^T Q = I, H = V Sigma V^T):
+  //     prox(Y) = U (Sigma - tau)_+ V^T = Q (H - tau I)_+ ,   (A)_+ = (A + |A|) / 2 ,  |A| = A sign(A).
+  // Both matrix functions come from Newton-Schulz iterations - odd cubics p(x) = a x + b x^3 applied
+  // to the singular values (X <- X (a I + b X^T X)) resp. eigenvalues (S <- S (a I + b S^2)) - with
+  // the equioscillating cubic of the current interval [l, 1] (p(l) = p(1), max p = 1: the lower end
+  // grows ~2.6x per step, l' = p(l) is known without looking at the matrix) and plain (3/2, -1/2)
+  // steps at the end.  What makes it exact enough in the presence of tiny singular values: the
+  // polar iteration only has to converge for sigma >= tau (a direction with sigma < tau ends with a
+  // factor q <= 1 in Q, its eigenvalue q sigma - tau of H - tau I is negative, the positive part
+  // drops it whatever q is), and the sign iteration only for |sigma - tau| above a resolution r
+  // (an unconverged sign s in (-1, 1) leaves an error <= r / 2 in that direction).  The few
+  // dominant, well separated triplets are taken out first by a randomized block (their prox is a
+  // rank-k update; prox(Y_top + Y_rest) = prox(Y_top) + prox(Y_rest) for orthogonal singular
+  // subspaces): the rounding of a product scales with ||Y_rest||_2, not with sigma_1.
+  // ~115 GEMMs of 1-2 n^3 flop on the split-f16 kernel at n = 1e4 (fp32: mostly monotone steps, see
+  // CubicOn), against 18 HBM-bound Jacobi sweeps;
+  // the result is held to the optimality condition of the prox afterwards (||P||_2 <= 1 and
+  // <X, P> = ||X||_* with P = (Y - X) / tau; ||X||_* = trace((H - tau I)_+) + the block's part):
+  // false sends the call to the Jacobi route.  (reference prox/ortho_invariant.cc:36-105 thresholds
+  // the singular values of an eigendecomposition of Y^T Y.)
+  // The equioscillating cubic is not monotone (it sends the top of the interval to the bottom),
+  // and a non-monotone step multiplies the rounding noise BETWEEN eigen-directions by its largest
+  // divided difference (~2.6) while the iteration only restores S^2 = I, not S = sign of the matrix
+  // it was given: in fp32 three such steps already cost 3e-4 ||Y_rest||_2 (measured in a strict
+  // float32 emulation and on the device), two cost nothing.  `amp` carries the product of the
+  // steps' bounds; past the budget (10 in fp32, 1e8 in fp64) the monotone (3/2, -1/2) step is used.
+  static void CubicOn(double l, double budget, double* amp, double* a, double* b) {
+    *a = 1.5;
+    *b = -0.5;
+    if (l > 0.95 || *amp * 2.6 > budget) return;
+    const double q = 1.0 + l + l * l, xs = std::sqrt(q / 3.0);
+    *a = 3.0 / (2.0 * xs);
+    *b = -*a / q;
+    *amp *= std::max(*a, std::fabs(*a + 3.0 * *b));
+  }
+
+  bool PolarNuclearProx(const DVec& y, double tau, DVec* Xout) {
+    Runtime& rt = Runtime::Get();
+    const int64_t m = m_, n = n_;
+    const DType dt = y.dt;
+    ProfScope prof("polar_prox", m, n);
+    static const bool trace = std::getenv("EPSILON_HIP_SVD_TRACE") != nullptr;
+    // ---- 1. the dominant block: randomized range finder (two power steps), small SVD
+    const int64_t k = 32;
+    DVec Z = DVec::Empty(n * k, dt), Q0 = DVec::Empty(m * k, dt);
+    k::FillHash(Z, 0x90A12ull);
+    k::Gemm(false, false, m, k, n, 1.0, y, m, Z, n, 0.0, Q0, m);
+    for (int it = 0; it < 2; ++it) {
+      Orthonormalise(Q0, m, k);
+      k::Gemm(true, false, n, k, m, 1.0, y, m, Q0, m, 0.0, Z, n);
+      Orthonormalise(Z, n, k);
+      k::Gemm(false, false, m, k, n, 1.0, y, m, Z, n, 0.0, Q0, m);
+    }
+    Orthonormalise(Q0, m, k);
+    DVec Wb = DVec::Empty(n * k, dt), Vb = DVec::Empty(k * k, dt);
+    k::Gemm(true, false, n, k, m, 1.0, y, m, Q0, m, 0.0, Wb, n);  // B^T = Y^T Q0 = Wb Vb^T
+    k::JacobiSvd(Wb, n, k, Vb, 40, false, false);
+    DVec sig = DVec::Empty(k, dt);
+    k::ColNorms(Wb, n, k, sig, false);
+    DVec U = DVec::Empty(m * k, dt);
+    k::Gemm(false, false, m, k, k, 1.0, Q0, m, Vb, k, 0.0, U, m);
+    std::vector<double> sh = sig.ToHost();
+    // residuals || Y (Wb_i / sigma_i) - sigma_i u_i || of the pairs
+    std::vector<double> keep(static_cast<size_t>(k), 0.0);
+    int64_t kd = 0;
+    {
+      DVec T = DVec::Empty(m * k, dt), U2 = U.Clone();
+      k::Gemm(false, false, m, k, n, 1.0, y, m, Wb, n, 0.0, T, m);
+      DVec one = DVec::Full(k, 1.0, dt), sig2 = DVec::Empty(k, dt);
+      k::DiagMul(sig2, 1.0, sig, sig, 0.0);
+      k::ColScaleByRatio(U2, m, k, one, sig2);
+      k::Axpby(T, -1.0, U2, 1.0);
+      DVec rn = DVec::Empty(k, dt);
+      k::ColNorms(T, m, k, rn, false);
+      const std::vector<double> rh = rn.ToHost();
+      double smax0 = 0, smin0 = sh[0];
+      for (double sv : sh) {
+        smax0 = std::max(smax0, sv);
+        smin0 = std::min(smin0, sv);
+      }
+      const double res_tol = dt == F32 ? 2e-5 : 1e-10;
+      // taken out: converged pairs that stand clear of the rest of the block
+      for (int64_t i = 0; i < k; ++i)
+        if (sh[i] > 2.0 * smin0 && sh[i] > 0 && rh[i] / sh[i] <= res_tol * smax0) {
+          keep[static_cast<size_t>(i)] = 1.0;
+          ++kd;
+        }
+    }
+    DVec mask = DVec::FromHost(keep.data(), k, dt), onek = DVec::Full(k, 1.0, dt);
+    k::ColScaleByRatio(U, m, k, onek, mask);  // columns of the pairs that stay in Y_rest become zero
+    DVec Yr = y.Clone();
+    if (kd > 0) k::Gemm(false, true, m, n, k, -1.0, U, m, Wb, n, 1.0, Yr, m);
+    // ---- 2. an upper bound of ||Y_rest||_2: power iteration (a lower bound) with a factor 1.5
+    // in hand - a factor costs log_2.6(1.5) = 0.4 steps, an underestimate would flip the sign of
+    // the top singular value under the aggressive cubic - capped by sqrt(||.||_1 ||.||_inf)
+    double est = 0;
+    {
+      DVec v = DVec::Empty(n, dt), w = DVec::Empty(m, dt);
+      k::FillHash(v, 0xC0FFEEull);
+      int slot = 0;
+      rt.ResetSlots();
+      slot = rt.NewSlot();
+      k::SumSq(v, rt.SlotPtr(slot), false);
+      k::ScaleByInvNorm(v, v, rt.SlotPtr(slot));
+      for (int it = 0; it < 30; ++it) {
+        k::Gemv(false, m, n, 1.0, Yr, m, v, 0.0, w);
+        k::Gemv(true, m, n, 1.0, Yr, m, w, 0.0, v);
+        slot = rt.NewSlot();
+        k::SumSq(v, rt.SlotPtr(slot), false);
+        k::ScaleByInvNorm(v, v, rt.SlotPtr(slot));
+      }
+      rt.FetchSlots();
+      est = std::sqrt(std::sqrt(rt.SlotValue(slot)));  // ||Y^T Y v|| -> sigma^2
+    }
+    if (!(est > 0) || !std::isfinite(est)) return false;
+    double smax = 1.5 * est;
+    {
+      auto col = rt.Alloc(static_cast<size_t>(std::max(m, n)) * sizeof(double));
+      std::vector<double> h(static_cast<size_t>(n));
+      k::ColAbsSums(Yr, m, n, m, static_cast<double*>(col->p));
+      EPS_HIP(hipMemcpyAsync(h.data(), col->p, h.size() * sizeof(double), hipMemcpyDeviceToHost, rt.stream()));
+      rt.Sync();
+      double l1 = 0;
+      for (double v : h) l1 = std::max(l1, v);
+      DVec Yt = DVec::Empty(m * n, dt);
+      k::MatCopy(true, n, m, 1.0, Yr, m, Yt);
+      h.resize(static_cast<size_t>(m));
+      k::ColAbsSums(Yt, n, m, n, static_cast<double*>(col->p));
+      EPS_HIP(hipMemcpyAsync(h.data(), col->p, h.size() * sizeof(double), hipMemcpyDeviceToHost, rt.stream()));
+      rt.Sync();
+      double linf = 0;
+      for (double v : h) linf = std::max(linf, v);
+      const double bound = std::sqrt(l1 * linf);
+      if (bound > 0 && bound < smax) smax = std::max(bound, est);
+    }
+    // fp32: the rounding of the products is ~6e-6 ||Y_rest||_2 per direction; beyond 1e4 tau it
+    // would show against the threshold (the Jacobi route resolves directions relative to sigma_i)
+    if (dt == F32 && smax > 2e4 * tau) return false;
+    if (trace)
+      std::fprintf(stderr, "[svd] polar route: %lld dominant triplets taken out, ||rest||_2 ~ %.4g (bound %.4g), tau %.4g\n",
+                   static_cast<long long>(kd), est, smax, tau);
+    // ---- 3. polar factor of Y_rest
+    const double noise_budget = dt == F32 ? 10.0 : 1e8;
+    DVec Xc = DVec::Empty(m * n, dt), Xn = DVec::Empty(m * n, dt);
+    k::Axpby(Xc, 1.0 / smax, Yr, 0.0);
+    DVec G = DVec::Empty(n * n, dt);
+    int steps = 0;
+    {
+      double l = 0.9 * tau / smax, amp = 1.0;
+      int tail = 0;
+      while (tail < 2 && steps < 80) {
+        double a, b;
+        CubicOn(l, noise_budget, &amp, &a, &b);
+        k::Gemm(true, false, n, n, m, b, Xc, m, Xc, m, 0.0, G, n, true);  // b X^T X (lower tiles)
+        k::SymmetrizeFromLower(G, n, n);
+        k::AddDiag(G, n, n, a, nullptr);
+        k::Gemm(false, false, m, n, n, 1.0, Xc, m, G, n, 0.0, Xn, m);
+        std::swap(Xc, Xn);
+        l = a * l + b * l * l * l;
+        if (a == 1.5 && l > 0.9999) ++tail;
+        ++steps;
+      }
+    }
+    Xn = DVec();
+    if (trace) {  // orthogonality of the polar factor (on everything that converged)
+      k::Gemm(true, false, n, n, m, 1.0, Xc, m, Xc, m, 0.0, G, n);
+      k::AddDiag(G, n, n, -1.0, nullptr);
+      rt.ResetSlots();
+      const int sl = rt.NewSlot();
+      k::SumSq(G, rt.SlotPtr(sl), false);
+      rt.FetchSlots();
+      std::fprintf(stderr, "[svd] polar route: ||Q^T Q - I||_F / sqrt(n) = %.3e after %d steps\n",
+                   std::sqrt(rt.SlotValue(sl) / static_cast<double>(n)), steps);
+    }
+    // ---- 4. A = sym(Q^T Y_rest) - tau I
+    DVec A = DVec::Empty(n * n, dt);
+    k::Gemm(true, false, n, n, m, 1.0, Xc, m, Yr, m, 0.0, A, n);
+    {
+      DVec At = DVec::Empty(n * n, dt);
+      k::MatCopy(true, n, n, 0.5, A, n, At);
+      k::Axpby(A, 1.0, At, 0.5);
+    }
+    k::AddDiag(A, n, n, -tau, nullptr);
+    // ---- 5. S = sign(A), resolution r around the threshold
+    const double amax = smax + tau;
+    const double res = std::max(1e-3 * tau, (dt == F32 ? 2e-6 : 1e-12) * amax);
+    DVec S = DVec::Empty(n * n, dt), Sn = DVec::Empty(n * n, dt);
+    k::Axpby(S, 1.0 / amax, A, 0.0);
+    int ssteps = 0;
+    {
+      double l = res / amax, amp = 1.0;
+      int tail = 0;
+      while (tail < 2 && ssteps < 120) {
+        double a, b;
+        CubicOn(l, noise_budget, &amp, &a, &b);
+        k::Gemm(true, false, n, n, n, b, S, n, S, n, 0.0, G, n, true);  // b S^2 = b S^T S (lower tiles)
+        k::SymmetrizeFromLower(G, n, n);
+        k::AddDiag(G, n, n, a, nullptr);
+        k::Gemm(false, false, n, n, n, 1.0, S, n, G, n, 0.0, Sn, n);
+        // keep S symmetric: S <- (Sn + Sn^T) / 2
+        k::MatCopy(true, n, n, 0.5, Sn, n, S);
+        k::Axpby(S, 0.5, Sn, 1.0);
+        l = a * l + b * l * l * l;
+        if (a == 1.5 && l > 0.9999) ++tail;
+        ++ssteps;
+      }
+    }
+    if (trace) {
+      k::Gemm(false, false, n, n, n, 1.0, S, n, S, n, 0.0, G, n);
+      k::AddDiag(G, n, n, -1.0, nullptr);
+      rt.ResetSlots();
+      const int sl = rt.NewSlot();
+      k::SumSq(G, rt.SlotPtr(sl), false);
+      rt.FetchSlots();
+      std::fprintf(stderr, "[svd] polar route: ||S^2 - I||_F / sqrt(n) = %.3e after %d steps\n",
+                   std::sqrt(rt.SlotValue(sl) / static_cast<double>(n)), ssteps);
+    }
+    // ---- 6. X_rest = Q (A + A S) / 2, plus the block's part
+    k::Gemm(false, false, n, n, n, 0.5, A, n, S, n, 0.0, Sn, n);
+    k::Axpby(Sn, 0.5, A, 1.0);  // (A)_+
+    S = DVec();
+    G = DVec();
+    DVec X = DVec::Empty(m * n, dt);
+    k::Gemm(false, false, m, n, n, 1.0, Xc, m, Sn, n, 0.0, X, m);
+    // trace((A)_+) = the nuclear norm of X_rest
+    double nuc = 0;
+    {
+      DVec dg = DVec::Empty(n, dt);
+      EPS_HIP(hipMemcpy2DAsync(dg.data(), DTypeSize(dt), Sn.data(), static_cast<size_t>(n + 1) * DTypeSize(dt),
+                               DTypeSize(dt), static_cast<size_t>(n), hipMemcpyDeviceToDevice, rt.stream()));
+      for (double v : dg.ToHost()) nuc += v;
+    }
+    if (kd > 0) {
+      DVec shr = DVec::Full(k, -tau, dt), pos = DVec::Empty(k, dt);
+      k::Axpby(shr, 1.0, sig, 1.0);
+      k::MaxZero(pos, shr);
+      k::ColScaleByRatio(U, m, k, sig, pos);  // u_i (sigma_i - tau)_+ / sigma_i (zero columns stay zero)
+      k::Gemm(false, true, m, n, k, 1.0, U, m, Wb, n, 1.0, X, m);
+      for (int64_t i = 0; i < k; ++i)
+        if (keep[static_cast<size_t>(i)] != 0.0) nuc += std::max(sh[static_cast<size_t>(i)] - tau, 0.0);
+    }
+    // ---- 7. the optimality condition of the result
+    double inner = 0, pnorm = 0;
+    {
+      DVec P = y.Clone();
+      k::Axpby(P, -1.0 / tau, X, 1.0 / tau);  // P = (Y - X) / tau
+      rt.ResetSlots();
+      const int sd = rt.NewSlot();
+      k::Dot(X, P, rt.SlotPtr(sd), false);
+      DVec v = DVec::Empty(n, dt), w = DVec::Empty(m, dt);
+      k::FillHash(v, 0xFACEull);
+      int slot = rt.NewSlot();
+      k::SumSq(v, rt.SlotPtr(slot), false);
+      k::ScaleByInvNorm(v, v, rt.SlotPtr(slot));
+      for (int it = 0; it < 20; ++it) {
+        k::Gemv(false, m, n, 1.0, P, m, v, 0.0, w);
+        k::Gemv(true, m, n, 1.0, P, m, w, 0.0, v);
+        slot = rt.NewSlot();
+        k::SumSq(v, rt.SlotPtr(slot), false);
+        k::ScaleByInvNorm(v, v, rt.SlotPtr(slot));
+      }
+      rt.FetchSlots();
+      inner = rt.SlotValue(sd);
+      pnorm = std::sqrt(std::sqrt(rt.SlotValue(slot)));
+    }
+    const double ptol = dt == F32 ? 2e-2 : 1e-6, itol = dt == F32 ? 2e-3 : 1e-8;
+    const bool ok = std::isfinite(pnorm) && std::isfinite(inner) && pnorm <= 1.0 + ptol &&
+                    std::fabs(inner - nuc) <= itol * std::max(nuc, tau);
+    if (trace)
+      std::fprintf(stderr, "[svd] polar route: %d + %d steps, ||P||_2 >= %.5f, <X,P> %.6g, ||X||_* %.6g: %s\n", steps,
+                   ssteps, pnorm, inner, nuc, ok ? "accepted" : "REJECTED");
+    if (!ok) return false;
+    *Xout = X;
+    return true;
+  }
+
   // Columns of Q (rows x k) <- an orthonormal basis of their span (one-sided Jacobi on the k
   // columns: Q = W V^T, the columns of W orthogonal; a numerically null column becomes zero).
   static void Orthonormalise(const DVec& Q, int64_t rows, int64_t k) {
@@ -733,6 +1031,10 @@ class OrthoInvariantProx : public VectorProx {
   // basis the previous application produced - right vectors (n x n) or left vectors (m x n)
   DVec basis_prev_;
   bool basis_is_left_ = false;
+  // polar route (PolarNuclearProx)
+  static constexpr int64_t kPolarMinSize = 1024;
+  static constexpr int64_t kPolarCalls = 4;
+  bool polar_enabled_ = true;
   int64_t calls_ = 0;
   bool warm_start_ = true;
   // thresholded partial SVD (nuclear-norm prox of a large matrix)

@@ -197,8 +197,8 @@ def test_nuclear_norm_prox_full_size_full_rank(solve_mod):
     """The same operator on the matrix the reference's robust-PCA generator produces
     (python/epopt/problems/robust_pca.py:5-22: rank-10 part + 10 % sparse part of 10 * randn) at
     10^4 x 10^4 with lam = 1: 99.8 % of the singular values exceed the threshold, so the thresholded
-    partial route gives up and the FULL decomposition runs (the planted-rank test above never
-    reaches it at this size).  Certificate: P = (Y - X) / lam has ||P||_2 <= 1 and <X, P> = ||X||_*
+    partial route gives up and the full-spectrum routes run - the GEMM-only polar route first, the
+    block Jacobi decomposition as its fallback (the planted-rank test above reaches neither).  Certificate: P = (Y - X) / lam has ||P||_2 <= 1 and <X, P> = ||X||_*
     (the nuclear norm of the full-rank X from torch's singular values on the device)."""
     from epsilon_amd.wire import ProxFunction
     n, r, lam = 10 ** 4, 10, 1.0
@@ -221,7 +221,9 @@ def test_nuclear_norm_prox_full_size_full_rank(solve_mod):
     tags = solve_mod.profile_dump()
     solve_mod.profile_enable(False)
     del yb
-    assert any(t.startswith("block_jacobi_svd") for t in tags), sorted(tags)  # the full decomposition ran
+    # the thresholded partial route cannot handle this spectrum: the GEMM-only polar route (round 3)
+    # or, had its certificate refused the result, the full decomposition ran
+    assert any(t.startswith(("polar_prox", "block_jacobi_svd")) for t in tags), sorted(tags)
     X = torch.from_numpy(np.frombuffer(got["var:X"]).reshape(n, n).copy()).to(dev).t()
     del got
     P = (Y - X) / lam

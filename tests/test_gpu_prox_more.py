@@ -498,6 +498,58 @@ def test_nuclear_norm_thresholded_partial_svd(solve_mod, dtype, case):
         assert full == (case in ("full_rank", "edge_at_threshold")), (case, names)
 
 
+@pytest.mark.parametrize("case", ["rpca", "bulk_only", "tall", "near_threshold"])
+def test_nuclear_norm_polar_route(solve_mod, dtype, case):
+    """Round 3: a nuclear-norm prox whose spectrum is (numerically) full above the threshold runs
+    on GEMMs only - polar factor Q of Y by Newton-Schulz, X = Q (H - tau I)_+ with the positive part
+    from the matrix sign function, the dominant outliers taken out first by a randomized block -
+    and is held to the optimality condition of the prox before it is returned
+    (prox_more.cc: PolarNuclearProx; reference prox/ortho_invariant.cc:36-105).  Against numpy's SVD:
+    the reference's robust-PCA matrix, a pure noise bulk, a tall matrix, and a spectrum with many
+    values within a per cent of the threshold (where the sign iteration is NOT converged and must
+    not matter)."""
+    from epsilon_amd import _solve
+    rng = np.random.RandomState(21)
+    if case == "rpca":
+        m = n = 1100
+        V = rng.randn(m, 10) @ rng.randn(10, n) + (rng.rand(m, n) < 0.1) * (10 * rng.randn(m, n))
+        lam = 1.0
+    elif case == "bulk_only":
+        m = n = 1056
+        V = rng.randn(m, n)
+        lam = 3.0
+    elif case == "tall":
+        m, n = 1500, 1030
+        V = rng.randn(m, 6) @ rng.randn(6, n) * 3 + rng.randn(m, n)
+        lam = 2.0
+    else:
+        m = n = 1040
+        U0, _ = np.linalg.qr(rng.randn(m, n))
+        V0, _ = np.linalg.qr(rng.randn(n, n))
+        sv0 = np.concatenate([np.linspace(0.98, 1.02, 400), np.linspace(1.5, 40, n - 400)])
+        V = (U0 * sv0) @ V0.T
+        lam = 1.0
+    X = ir.variable(m, n, "var:X")
+    e = ir.prox(ProxFunction.NORM_NUCLEAR, X)
+    _solve.profile_enable(True)
+    _solve.profile_reset()
+    got = solve_mod.eval_prox(e.proto.SerializeToString(), lam, e.data, {"var:X": V.reshape(-1, order="F").tobytes()})
+    tags = _solve.profile_dump()
+    _solve.profile_enable(False)
+    G = np.frombuffer(got["var:X"]).reshape((m, n), order="F")
+    U, sv, Vt = np.linalg.svd(V, full_matrices=False)
+    want = (U * np.maximum(sv - lam, 0)) @ Vt
+    assert any(t.startswith("polar_prox") for t in tags), sorted(tags)
+    # the decomposition must NOT have run: the polar route's own certificate accepted the result
+    assert not any(t.startswith(("block_jacobi_svd:%dx%d" % (m, n), "block_jacobi_svd_no_v:%dx%d" % (m, n)))
+                   for t in tags), sorted(tags)
+    err = np.linalg.norm(G - want, 2)
+    # fp32: rounding of the products ~6e-6 ||Y_rest||_2 per direction; an unconverged sign within the
+    # resolution (1e-3 lam) of the threshold costs <= 5e-4 lam in that direction
+    tol = (1e-8 if dtype == "f64" else 2e-5) * sv[0] + (1e-3 * lam if case == "near_threshold" else 0.0)
+    assert err <= tol, (case, err, tol)
+
+
 @pytest.mark.parametrize("name", ["max", "sum_largest_9", "log_sum_exp"])
 @pytest.mark.parametrize("shape", [(200001, 1), (3, 150000)])
 def test_vector_prox_long_slices(solve_mod, dtype, name, shape):
