@@ -31,6 +31,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 #include "kernels.h"
 
@@ -46,6 +50,7 @@ constexpr int TS = 256;       // tile rows / columns
 constexpr int SK = 32;        // k slab
 constexpr int LROW = 40;      // LDS row stride in halfs (80 bytes)
 constexpr int kThreads = 512;
+constexpr int kStagePerGroup = 2;  // V == 2: staging loads issued after each of the first groups
 
 // ---- max_k |a_ik| per row (bit pattern of a non-negative float: integer order = float order) -------
 __global__ __launch_bounds__(256) void RowAbsMaxKernel(const float* __restrict__ A, int64_t M, int64_t K,
@@ -177,13 +182,33 @@ struct SplitOperand {
 // ---- the product -----------------------------------------------------------------------------------
 // C (M x N) = alpha * X_a X_b^T + beta * C with X_a = op(A) (rows i), X_b = op(B)^T (rows j).
 // tri != 0: M == N and only the tiles on and below the diagonal (compact 1-D grid, lin0 offset).
+// `order` (optional): the tiles as packed (I << 16 | J) words in PATCH-MAJOR order (8 x 8 patches,
+// row-major inside), and workgroup -> tile through the XCD-aware permutation below.  Workgroups
+// are dealt round-robin over the 8 XCDs (b and b + 8 share one L2) and a CU holds one of them,
+// so the 32 that an XCD runs together are slots [32 r, 32 r + 32) of its own sequence: with the
+// permutation those are 4 x 8 neighbouring tiles - 12 operand panels for 32 tiles in that L2
+// instead of ~40 (every panel of the matrix).  The product is bound by the latency of its staging
+// loads (one slab in flight), and a load that hits the XCD's L2 returns in a third of the time.
+// V = 0: register-staged slabs (one in flight), padded LDS image, two barriers per slab.
+// V = 1: LDS-DMA staging (global_load_lds, no staging registers, no LDS write pass), two LDS
+// buffers, XOR-swizzled image, one barrier per slab.
+template <int V>
 __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
     int64_t M, int64_t N, int64_t nslab, SplitOperand oa, SplitOperand ob, float alpha, float beta, float* C,
-    int64_t ldc, int tri, int64_t lin0, int64_t slab0, int64_t slab_count, float* __restrict__ P) {
-  __shared__ __attribute__((aligned(16))) _Float16 sm[4][TS * LROW];  // H_I, L_I, H_J, L_J: 80 KB
+    int64_t ldc, int tri, int64_t lin0, int64_t slab0, int64_t slab_count, float* __restrict__ P,
+    const int* __restrict__ order, int64_t perm_limit) {
   const int64_t lin = lin0 + blockIdx.x;
   int64_t I, J;
-  if (tri == 1 || tri == 2) {  // tile (I, J), I >= J, from the linear index over the lower triangle
+  if (order != nullptr) {
+    int64_t tpos = lin;
+    if (lin < perm_limit) {  // perm_limit is a multiple of 256: a bijection of [0, perm_limit)
+      const int64_t xcd = lin & 7, slot = lin >> 3;
+      tpos = ((((slot >> 5) << 3) + xcd) << 5) + (slot & 31);
+    }
+    const int w = order[tpos];
+    I = w >> 16;
+    J = w & 0xffff;
+  } else if (tri == 1 || tri == 2) {  // tile (I, J), I >= J, from the linear index over the lower triangle
     I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= lin) ++I;
     while (I * (I + 1) / 2 > lin) --I;
@@ -222,64 +247,324 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  // staging: a slab of one array and one side is 256 rows x 64 bytes = 1024 lane loads of 16 B,
-  // two per thread; q = t + 512 p -> row q >> 2, segment q & 3
-  half8 pre[4][2];
-  auto gload = [&](int64_t ks) {
-    const _Float16* hI = oa.H + (ks * oa.rows_pad + i0) * SK;
-    const _Float16* lI = oa.L + (ks * oa.rows_pad + i0) * SK;
-    const _Float16* hJ = ob.H + (ks * ob.rows_pad + j0) * SK;
-    const _Float16* lJ = ob.L + (ks * ob.rows_pad + j0) * SK;
+  if constexpr (V == 3) {
+    // V == 3: a RING of four 16-deep steps (4 x 4 arrays x 256 rows x 32 bytes = 128 KB), the
+    // barrier in the MIDDLE of a step's matrix instructions and the next step's fragments read
+    // into a second register set - nothing at a step boundary waits.  Step s computes from buffer
+    // s & 3.  B(s), the barrier inside step s, is preceded by `vmcnt(4)`: this wave's pieces of
+    // step s + 1 have landed (the 4 of step s + 2 may still fly), so behind B(s) every wave may
+    // read step s + 1 - and every wave has left step s - 1, whose buffer is the one step s + 3
+    // goes to: its 4 loads are issued right behind B(s) and have two whole steps to land.
+    //   issue stage(u) after B(u - 3);  wait for it before B(u - 1);  read it after B(u - 1).
+    // Past the last step the stream stays branch-free: the last step is staged again (into
+    // buffers nobody reads any more) and drained before the epilogue.
+    // LDS image of an array and step: the 32-byte row pieces in row order (what a wave's DMA of
+    // 32 rows x 2 x 16 bytes writes), the two 16-byte halves of a row swapped where (row >> 3) & 1:
+    // the 16 lanes of a fragment read (16 rows, one half) cover the 16 slots of a bank row.
+    __shared__ __attribute__((aligned(16))) _Float16 ring[4][4][TS * 16];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int arr_w = wave_u & 3, pg = wave_u >> 2;  // this wave stages rows pg*128 .. +128 of array arr_w
+    int src_off[4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int q = t + kThreads * p;
-      pre[0][p] = *reinterpret_cast<const half8*>(hI + q * 8);
-      pre[1][p] = *reinterpret_cast<const half8*>(lI + q * 8);
-      pre[2][p] = *reinterpret_cast<const half8*>(hJ + q * 8);
-      pre[3][p] = *reinterpret_cast<const half8*>(lJ + q * 8);
+    for (int q = 0; q < 4; ++q) {
+      const int slot = (pg * 4 + q) * 64 + lane;
+      const int row = slot >> 1, seg = (slot & 1) ^ ((row >> 3) & 1);
+      src_off[q] = row * SK + seg * 8;
     }
-  };
-  auto lstore = [&]() {
+    const _Float16* arr_base = arr_w == 0   ? oa.H + i0 * SK
+                               : arr_w == 1 ? oa.L + i0 * SK
+                               : arr_w == 2 ? ob.H + j0 * SK
+                                            : ob.L + j0 * SK;
+    const int64_t arr_stride = (arr_w < 2 ? oa.rows_pad : ob.rows_pad) * SK;  // halfs per slab
+    const int64_t nsteps = ks1 > ks0 ? 2 * (ks1 - ks0) : 0;
+    auto stage_src = [&](int64_t step) {  // scalar arithmetic: placed IN FRONT of the barrier
+      const int64_t sc = step < nsteps ? step : nsteps - 1;
+      return arr_base + (ks0 + (sc >> 1)) * arr_stride + (sc & 1) * 16;
+    };
+    auto stage_issue = [&](int64_t step, const _Float16* src) {
+      _Float16* dst = &ring[step & 3][arr_w][pg * 4 * 512];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int q = t + kThreads * p;
-      const int off = (q >> 2) * LROW + (q & 3) * 8;
-#pragma unroll
-      for (int arr = 0; arr < 4; ++arr) *reinterpret_cast<half8*>(&sm[arr][off]) = pre[arr][p];
-    }
-  };
-  if (ks0 < ks1) gload(ks0);
-  for (int64_t ks = ks0; ks < ks1; ++ks) {
-    __syncthreads();  // the previous slab's fragment reads are done
-    lstore();
-    __syncthreads();
-    if (ks + 1 < ks1) gload(ks + 1);  // in flight under this slab's MFMAs
-#pragma unroll
-    for (int kk = 0; kk < SK; kk += 16) {
-      half8 ih[4], il[4], jh[2], jl[2];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int off = (wi * 128 + a * 32 + l31) * LROW + kk + 8 * lh;
-        ih[a] = *reinterpret_cast<const half8*>(&sm[0][off]);
-        il[a] = *reinterpret_cast<const half8*>(&sm[1][off]);
-      }
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + src_off[q]),
+                                         (__attribute__((address_space(3))) void*)(dst + q * 512), 16, 0, 0);
+    };
+    auto stage = [&](int64_t step) { stage_issue(step, stage_src(step)); };
+    const int sw = (l31 >> 3) & 1;
+    const int fragI = (wi * 128 + l31) * 16 + ((lh ^ sw) << 3);  // + a * 512
+    const int fragJ = (wj * 64 + l31) * 16 + ((lh ^ sw) << 3);   // + b * 512
+    auto readf = [&](int64_t step, half8(&ih)[4], half8(&il)[4], half8(&jh)[2], half8(&jl)[2]) {
+      const _Float16* B = &ring[step & 3][0][0];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int off = (wj * 64 + b * 32 + l31) * LROW + kk + 8 * lh;
-        jh[b] = *reinterpret_cast<const half8*>(&sm[2][off]);
-        jl[b] = *reinterpret_cast<const half8*>(&sm[3][off]);
+        jh[b] = *reinterpret_cast<const half8*>(B + 2 * TS * 16 + fragJ + b * 512);
+        jl[b] = *reinterpret_cast<const half8*>(B + 3 * TS * 16 + fragJ + b * 512);
       }
-      // D'[j][i] += X_J[j][k] X_I[i][k]: the MFMA's "A" operand takes the J side, so a register's
-      // lanes run along i - consecutive rows of column-major C
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a) {
+        ih[a] = *reinterpret_cast<const half8*>(B + fragI + a * 512);
+        il[a] = *reinterpret_cast<const half8*>(B + TS * 16 + fragI + a * 512);
+      }
+    };
+    // 12 matrix instructions: the three product terms on the four accumulators of row blocks ap, ap + 1
+    auto half_step = [&](int ap, const half8(&ih)[4], const half8(&il)[4], const half8(&jh)[2],
+                         const half8(&jl)[2]) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], ih[a], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], il[a], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jl[b], ih[a], acc[a][b], 0, 0, 0);
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int a = ap; a < ap + 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 2 ? jl[b] : jh[b], term == 1 ? il[a] : ih[a],
+                                                               acc[a][b], 0, 0, 0);
+    };
+    if (nsteps > 0) {
+      half8 aih[4], ail[4], ajh[2], ajl[2], bih[4], bil[4], bjh[2], bjl[2];
+      stage(0);
+      stage(1);
+      stage(2);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      readf(0, aih, ail, ajh, ajl);
+      auto body = [&](int64_t st, const half8(&cih)[4], const half8(&cil)[4], const half8(&cjh)[2],
+                      const half8(&cjl)[2], half8(&nih)[4], half8(&nil)[4], half8(&njh)[2], half8(&njl)[2]) {
+        const _Float16* nsrc = stage_src(st + 3);
+        half_step(0, cih, cil, cjh, cjl);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stage_issue(st + 3, nsrc);
+        readf(st + 1, nih, nil, njh, njl);
+        half_step(2, cih, cil, cjh, cjl);
+        // issue order behind the barrier: the 4 staging loads and the 12 fragment reads between
+        // the matrix instructions (whose pipe time hides their issue), not in front of them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int64_t st = 0; st < nsteps; st += 2) {
+        body(st, aih, ail, ajh, ajl, bih, bil, bjh, bjl);
+        body(st + 1, bih, bil, bjh, bjl, aih, ail, ajh, ajl);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS
     }
+  } else if constexpr (V >= 1) {
+    // two buffers x (H_I, L_I, H_J, L_J) x 256 rows x 64 bytes = 128 KB.  A wave-instruction of
+    // the LDS-DMA writes 64 x 16 bytes contiguously (16 rows), so the image is the global slab's
+    // own order; the conflict-free form comes from a permutation of the four 16-byte segments of
+    // a row, applied to the SOURCE address of the load and to the fragment read alike:
+    // slot(row, seg) = 4 row + (seg ^ ((row >> 2) & 3)) - the 16 lanes of a ds_read_b128 group
+    // (16 consecutive rows, one segment) then cover all 16 slots of the 256-byte bank row.
+    __shared__ __attribute__((aligned(16))) _Float16 sm2[2][4][TS * SK];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this thread's two pieces of an array: LDS slots wi * 64 + lane, wi = 2 wave + q
+    int src_off[2];  // in halfs, inside the 256-row slab of one array
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int slot = (wave_u * 2 + q) * 64 + lane;
+      const int row = slot >> 2, seg = (slot & 3) ^ ((row >> 2) & 3);
+      src_off[q] = row * SK + seg * 8;
+    }
+    auto stage = [&](int buf, int64_t ks) {
+      const _Float16* base[4] = {oa.H + (ks * oa.rows_pad + i0) * SK, oa.L + (ks * oa.rows_pad + i0) * SK,
+                                 ob.H + (ks * ob.rows_pad + j0) * SK, ob.L + (ks * ob.rows_pad + j0) * SK};
+#pragma unroll
+      for (int arr = 0; arr < 4; ++arr)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(base[arr] + src_off[q]),
+              (__attribute__((address_space(3))) void*)(&sm2[buf][arr][(wave_u * 2 + q) * 512]), 16, 0, 0);
+    };
+    // fragment offsets (halfs) of this lane inside an array: row-dependent part and the swizzle
+    int offI[4], offJ[2], swI[4], swJ[2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int row = wi * 128 + a * 32 + l31;
+      offI[a] = row * SK;
+      swI[a] = (row >> 2) & 3;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int row = wj * 64 + b * 32 + l31;
+      offJ[b] = row * SK;
+      swJ[b] = (row >> 2) & 3;
+    }
+    int cur = 0;
+    if (ks0 < ks1) {
+      stage(0, ks0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if constexpr (V == 1) {
+      for (int64_t ks = ks0; ks < ks1; ++ks) {
+        if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);  // lands under this slab's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < SK; kk += 16) {
+          half8 ih[4], il[4], jh[2], jl[2];
+          const int seg = kk / 8 + lh;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int off = offI[a] + ((seg ^ swI[a]) << 3);
+            ih[a] = *reinterpret_cast<const half8*>(&sm2[cur][0][off]);
+            il[a] = *reinterpret_cast<const half8*>(&sm2[cur][1][off]);
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int off = offJ[b] + ((seg ^ swJ[b]) << 3);
+            jh[b] = *reinterpret_cast<const half8*>(&sm2[cur][2][off]);
+            jl[b] = *reinterpret_cast<const half8*>(&sm2[cur][3][off]);
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], ih[a], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], il[a], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jl[b], ih[a], acc[a][b], 0, 0, 0);
+            }
+        }
+        // the matrix instructions are issued (their fragment reads have returned) before the
+        // barrier: a wave past it overwrites this buffer
+        __builtin_amdgcn_sched_barrier(0);
+        // the next slab has landed (this wave's pieces), every wave is done reading this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+      }
+    } else {
+      // V == 2: the same slab step with its issue order pinned.  All 24 fragment reads of the
+      // slab first (two register sets: the LDS latency is paid once per slab), then groups of
+      // four INDEPENDENT matrix instructions (one product term on the four accumulators of a
+      // pair of row blocks); the staging loads of the next slab go between the first groups, one
+      // or two per group, where their issue time hides behind the matrix pipe instead of in front
+      // of it.  The last iteration re-stages its own slab (a branch-free stream; 64 KB wasted per
+      // tile).
+      for (int64_t ks = ks0; ks < ks1; ++ks) {
+        const int64_t ksn = ks + 1 < ks1 ? ks + 1 : ks;
+        const _Float16* nb[4] = {oa.H + (ksn * oa.rows_pad + i0) * SK, oa.L + (ksn * oa.rows_pad + i0) * SK,
+                                 ob.H + (ksn * ob.rows_pad + j0) * SK, ob.L + (ksn * ob.rows_pad + j0) * SK};
+        half8 ih[2][4], il[2][4], jh[2][2], jl[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int seg = 2 * h + lh;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int off = offJ[b] + ((seg ^ swJ[b]) << 3);
+            jh[h][b] = *reinterpret_cast<const half8*>(&sm2[cur][2][off]);
+            jl[h][b] = *reinterpret_cast<const half8*>(&sm2[cur][3][off]);
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int off = offI[a] + ((seg ^ swI[a]) << 3);
+            ih[h][a] = *reinterpret_cast<const half8*>(&sm2[cur][0][off]);
+            il[h][a] = *reinterpret_cast<const half8*>(&sm2[cur][1][off]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int piece = 0;  // compile-time after unrolling
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ap = 0; ap < 4; ap += 2)
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+              for (int a = ap; a < ap + 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                  const half8 fj = term == 2 ? jl[h][b] : jh[h][b];
+                  const half8 fi = term == 1 ? il[h][a] : ih[h][a];
+                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fj, fi, acc[a][b], 0, 0, 0);
+                }
+#pragma unroll
+              for (int rep = 0; rep < kStagePerGroup; ++rep)
+                if (piece < 8) {
+                  const int arr = piece >> 1, q = piece & 1;
+                  __builtin_amdgcn_global_load_lds(
+                      (const __attribute__((address_space(1))) void*)(nb[arr] + src_off[q]),
+                      (__attribute__((address_space(3))) void*)(&sm2[cur ^ 1][arr][(wave_u * 2 + q) * 512]), 16, 0,
+                      0);
+                  ++piece;
+                }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+      }
+    }
+  } else {
+    // staging: a slab of one array and one side is 256 rows x 64 bytes = 1024 lane loads of 16 B,
+    // two per thread; q = t + 512 p -> row q >> 2, segment q & 3
+    __shared__ __attribute__((aligned(16))) _Float16 sm[4][TS * LROW];  // H_I, L_I, H_J, L_J: 80 KB
+    half8 pre[4][2];
+    auto gload = [&](int64_t ks) {
+      const _Float16* hI = oa.H + (ks * oa.rows_pad + i0) * SK;
+      const _Float16* lI = oa.L + (ks * oa.rows_pad + i0) * SK;
+      const _Float16* hJ = ob.H + (ks * ob.rows_pad + j0) * SK;
+      const _Float16* lJ = ob.L + (ks * ob.rows_pad + j0) * SK;
+  #pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int q = t + kThreads * p;
+        pre[0][p] = *reinterpret_cast<const half8*>(hI + q * 8);
+        pre[1][p] = *reinterpret_cast<const half8*>(lI + q * 8);
+        pre[2][p] = *reinterpret_cast<const half8*>(hJ + q * 8);
+        pre[3][p] = *reinterpret_cast<const half8*>(lJ + q * 8);
+      }
+    };
+    auto lstore = [&]() {
+  #pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int q = t + kThreads * p;
+        const int off = (q >> 2) * LROW + (q & 3) * 8;
+  #pragma unroll
+        for (int arr = 0; arr < 4; ++arr) *reinterpret_cast<half8*>(&sm[arr][off]) = pre[arr][p];
+      }
+    };
+    if (ks0 < ks1) gload(ks0);
+    for (int64_t ks = ks0; ks < ks1; ++ks) {
+      __syncthreads();  // the previous slab's fragment reads are done
+      lstore();
+      __syncthreads();
+      if (ks + 1 < ks1) gload(ks + 1);  // in flight under this slab's MFMAs
+  #pragma unroll
+      for (int kk = 0; kk < SK; kk += 16) {
+        half8 ih[4], il[4], jh[2], jl[2];
+  #pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int off = (wi * 128 + a * 32 + l31) * LROW + kk + 8 * lh;
+          ih[a] = *reinterpret_cast<const half8*>(&sm[0][off]);
+          il[a] = *reinterpret_cast<const half8*>(&sm[1][off]);
+        }
+  #pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int off = (wj * 64 + b * 32 + l31) * LROW + kk + 8 * lh;
+          jh[b] = *reinterpret_cast<const half8*>(&sm[2][off]);
+          jl[b] = *reinterpret_cast<const half8*>(&sm[3][off]);
+        }
+        // D'[j][i] += X_J[j][k] X_I[i][k]: the MFMA's "A" operand takes the J side, so a register's
+        // lanes run along i - consecutive rows of column-major C
+  #pragma unroll
+        for (int a = 0; a < 4; ++a)
+  #pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], ih[a], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jh[b], il[a], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jl[b], ih[a], acc[a][b], 0, 0, 0);
+          }
+      }
+    }
+
   }
 
   // raw partial tile of a split-K tail: scales and beta are the fix-up kernel's
@@ -338,12 +623,20 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
 __global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64_t lin0, int S,
                                                                 const float* __restrict__ P,
                                                                 const unsigned* __restrict__ rowmax_bits,
-                                                                float alpha, float beta, float* C, int64_t ldc) {
+                                                                float alpha, float beta, float* C, int64_t ldc,
+                                                                const int* __restrict__ order) {
   const int64_t lin = lin0 + blockIdx.x;
-  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
-  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
-  while (I * (I + 1) / 2 > lin) --I;
-  const int64_t i0 = I * TS, j0 = (lin - I * (I + 1) / 2) * TS;
+  int64_t I, Jt;
+  if (order != nullptr) {  // the tail tiles keep their place in the order table
+    I = order[lin] >> 16;
+    Jt = order[lin] & 0xffff;
+  } else {
+    I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+    while (I * (I + 1) / 2 > lin) --I;
+    Jt = lin - I * (I + 1) / 2;
+  }
+  const int64_t i0 = I * TS, j0 = Jt * TS;
   const float* p0 = P + static_cast<int64_t>(blockIdx.x) * S * (TS * TS);
   // gridDim.y workgroups share a tile (one each left 50 workgroups on the chip with 256 dependent
   // iterations per thread: 236 us for the Gram's tail at config 2)
@@ -368,6 +661,73 @@ struct ConvertedOperand {
   std::shared_ptr<Buffer> h, l, mx;
   SplitOperand op;
 };
+
+// EPSILON_HIP_GEMM_STAGE = reg: the register-staged loop (V = 0); EPSILON_HIP_GEMM_ORDER = 0: tiles
+// in plain linear order.  Read on every call (the microbenchmark switches them between launches).
+int StageVariant() {
+  const char* e = std::getenv("EPSILON_HIP_GEMM_STAGE");
+  if (e == nullptr) return 3;
+  if (std::strcmp(e, "reg") == 0) return 0;  // register-staged, padded image (round 2)
+  if (std::strcmp(e, "lds") == 0) return 1;  // LDS-DMA, two 32-deep buffers, compiler-scheduled
+  if (std::strcmp(e, "pin") == 0) return 2;  // the same with its issue order pinned
+  return 3;                                   // "ring": four 16-deep steps
+}
+bool PatchOrderEnabled() {
+  const char* e = std::getenv("EPSILON_HIP_GEMM_ORDER");
+  return !(e != nullptr && e[0] == '0');
+}
+
+// The tiles of a TI x TJ grid (lower: J <= I only) in patch-major order, as (I << 16 | J) words on
+// the device.  Built once per shape and kept for the life of the process (a few KB each).
+const int* TileOrder(int64_t TI, int64_t TJ, bool lower, int64_t* count) {
+  struct Entry {
+    std::shared_ptr<Buffer> buf;
+    int64_t count;
+  };
+  static std::mutex mu;
+  static auto* cache = new std::map<std::tuple<int64_t, int64_t, bool>, Entry>();  // never destroyed
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_tuple(TI, TJ, lower);
+  auto it = cache->find(key);
+  if (it == cache->end()) {
+    EPS_CHECK(TI < 65536 && TJ < 65536);
+    std::vector<int> h;
+    constexpr int64_t PS = 8;
+    for (int64_t pr = 0; pr * PS < TI; ++pr)
+      for (int64_t pc = 0; pc * PS < TJ; ++pc) {
+        if (lower && pc > pr) continue;
+        for (int64_t i = pr * PS; i < std::min(TI, (pr + 1) * PS); ++i)
+          for (int64_t j = pc * PS; j < std::min(TJ, (pc + 1) * PS); ++j)
+            if (!lower || j <= i) h.push_back(static_cast<int>((i << 16) | j));
+      }
+    Entry e;
+    e.count = static_cast<int64_t>(h.size());
+    e.buf = Runtime::Get().Alloc(h.size() * sizeof(int));
+    EPS_HIP(hipMemcpy(e.buf->p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+    it = cache->emplace(key, std::move(e)).first;
+  }
+  *count = it->second.count;
+  return static_cast<const int*>(it->second.buf->p);
+}
+
+void LaunchSplit(dim3 grid, int64_t M, int64_t N, int64_t nslab, const SplitOperand& oa, const SplitOperand& ob,
+                 float al, float be, float* C, int64_t ldc, int tri, int64_t lin0, int64_t slab0, int64_t slab_count,
+                 float* P, const int* order, int64_t perm_limit) {
+  hipStream_t s = Runtime::Get().stream();
+  const int v = StageVariant();
+  if (v == 3)
+    hipLaunchKernelGGL(GemmSplitF16Kernel<3>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
+                       lin0, slab0, slab_count, P, order, perm_limit);
+  else if (v == 2)
+    hipLaunchKernelGGL(GemmSplitF16Kernel<2>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
+                       lin0, slab0, slab_count, P, order, perm_limit);
+  else if (v == 1)
+    hipLaunchKernelGGL(GemmSplitF16Kernel<1>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
+                       lin0, slab0, slab_count, P, order, perm_limit);
+  else
+    hipLaunchKernelGGL(GemmSplitF16Kernel<0>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
+                       lin0, slab0, slab_count, P, order, perm_limit);
+}
 
 // X holds `rows` rows of K entries: element (r, k) at X[r + k * ld] (contig_r) or X[k + r * ld].
 ConvertedOperand ConvertOperand(const float* X, int64_t rows, int64_t K, int64_t ld, bool contig_r) {
@@ -439,14 +799,17 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
   const SplitOperand& ob = same ? ca.op : cb.op;
   const float al = static_cast<float>(alpha), be = static_cast<float>(beta);
   const int64_t TI = (M + TS - 1) / TS, TJ = (N + TS - 1) / TS;
+  int64_t ocount = 0;
+  const int* order = PatchOrderEnabled() ? TileOrder(TI, TJ, lower_only, &ocount) : nullptr;
   if (!lower_only) {
-    hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(TI * TJ)), dim3(kThreads), 0, s, M, N, nslab,
-                       oa, ob, al, be, C.as<float>(), ldc, 0, static_cast<int64_t>(0), static_cast<int64_t>(0),
-                       nslab, static_cast<float*>(nullptr));
+    EPS_CHECK(order == nullptr || ocount == TI * TJ);
+    LaunchSplit(dim3(static_cast<unsigned>(TI * TJ)), M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, 0, 0, 0, nslab,
+                nullptr, order, TI * TJ / 256 * 256);
     EPS_HIP(hipGetLastError());
     return true;
   }
   const int64_t total = TI * (TI + 1) / 2;
+  EPS_CHECK(order == nullptr || ocount == total);
   // one 512-thread workgroup per CU: rounds of 256 tiles; a ragged last round of a LONG
   // contraction is split over K
   const int64_t slots = 256;
@@ -462,17 +825,15 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
   }
   const int64_t full = total - tail;
   if (full > 0)
-    hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(full)), dim3(kThreads), 0, s, M, N, nslab, oa,
-                       ob, al, be, C.as<float>(), ldc, 1, static_cast<int64_t>(0), static_cast<int64_t>(0), nslab,
-                       static_cast<float*>(nullptr));
+    LaunchSplit(dim3(static_cast<unsigned>(full)), M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, 1, 0, 0, nslab,
+                nullptr, order, full / 256 * 256);
   if (tail > 0) {
     auto pbuf = rt.Alloc(static_cast<size_t>(tail) * S * TS * TS * sizeof(float));
     float* P = static_cast<float*>(pbuf->p);
-    hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(tail), static_cast<unsigned>(S)),
-                       dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, 1, full,
-                       static_cast<int64_t>(0), per, P);
+    LaunchSplit(dim3(static_cast<unsigned>(tail), static_cast<unsigned>(S)), M, N, nslab, oa, ob, al, be,
+                C.as<float>(), ldc, 1, full, 0, per, P, order, 0);
     hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail), 16), dim3(256), 0, s, M, full, S,
-                       P, oa.rowmax, al, be, C.as<float>(), ldc);
+                       P, oa.rowmax, al, be, C.as<float>(), ldc, order);
   }
   EPS_HIP(hipGetLastError());
   return true;
@@ -494,9 +855,8 @@ bool GemmSplitF16KRange(int kmode, int64_t M, int64_t N, int64_t K, double alpha
   ConvertedOperand ca = ConvertOperand(A.as<float>(), M, K, lda, true);   // A(i, k) = A[i + k lda]
   ConvertedOperand cb = ConvertOperand(B.as<float>(), N, K, ldb, false);  // B(k, j) = B[k + j ldb]
   const int64_t TI = (M + TS - 1) / TS, TJ = (N + TS - 1) / TS;
-  hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(TI * TJ)), dim3(kThreads), 0, s, M, N, nslab,
-                     ca.op, cb.op, static_cast<float>(alpha), 0.0f, C.as<float>(), ldc, kmode,
-                     static_cast<int64_t>(0), static_cast<int64_t>(0), nslab, static_cast<float*>(nullptr));
+  LaunchSplit(dim3(static_cast<unsigned>(TI * TJ)), M, N, nslab, ca.op, cb.op, static_cast<float>(alpha), 0.0f,
+              C.as<float>(), ldc, kmode, 0, 0, nslab, nullptr, nullptr, 0);
   EPS_HIP(hipGetLastError());
   return true;
 }
@@ -513,9 +873,8 @@ bool SyrkSplitF16LowerTriangular(int64_t n, const DVec& X, int64_t ldx, const DV
   const int64_t nslab = (n + SK - 1) / SK;
   ConvertedOperand cx = ConvertOperand(X.as<float>(), n, n, ldx, false);  // rows = columns of X
   const int64_t T = (n + TS - 1) / TS;
-  hipLaunchKernelGGL(GemmSplitF16Kernel, dim3(static_cast<unsigned>(T * (T + 1) / 2)), dim3(kThreads), 0, s, n, n,
-                     nslab, cx.op, cx.op, 1.0f, 0.0f, C.as<float>(), ldc, 2, static_cast<int64_t>(0),
-                     static_cast<int64_t>(0), nslab, static_cast<float*>(nullptr));
+  LaunchSplit(dim3(static_cast<unsigned>(T * (T + 1) / 2)), n, n, nslab, cx.op, cx.op, 1.0f, 0.0f, C.as<float>(), ldc,
+              2, 0, 0, nslab, nullptr, nullptr, 0);
   EPS_HIP(hipGetLastError());
   return true;
 }

@@ -766,10 +766,11 @@ class OrthoInvariantProx : public VectorProx {
         k::Gemm(true, false, n, n, n, b, S, n, S, n, 0.0, G, n, true);  // b S^2 = b S^T S (lower tiles)
         k::SymmetrizeFromLower(G, n, n);
         k::AddDiag(G, n, n, a, nullptr);
-        k::Gemm(false, false, n, n, n, 1.0, S, n, G, n, 0.0, Sn, n);
-        // keep S symmetric: S <- (Sn + Sn^T) / 2
-        k::MatCopy(true, n, n, 0.5, Sn, n, S);
-        k::Axpby(S, 0.5, Sn, 1.0);
+        // S G = a S + b S^3 is symmetric: the lower tiles only, mirrored (half the product, and S
+        // stays exactly symmetric)
+        k::Gemm(false, false, n, n, n, 1.0, S, n, G, n, 0.0, Sn, n, true);
+        k::SymmetrizeFromLower(Sn, n, n);
+        std::swap(S, Sn);
         l = a * l + b * l * l * l;
         if (a == 1.5 && l > 0.9999) ++tail;
         ++ssteps;
@@ -786,7 +787,8 @@ class OrthoInvariantProx : public VectorProx {
                    std::sqrt(rt.SlotValue(sl) / static_cast<double>(n)), ssteps);
     }
     // ---- 6. X_rest = Q (A + A S) / 2, plus the block's part
-    k::Gemm(false, false, n, n, n, 0.5, A, n, S, n, 0.0, Sn, n);
+    k::Gemm(false, false, n, n, n, 0.5, A, n, S, n, 0.0, Sn, n, true);  // A S = |A|: symmetric
+    k::SymmetrizeFromLower(Sn, n, n);
     k::Axpby(Sn, 0.5, A, 1.0);  // (A)_+
     S = DVec();
     G = DVec();
