@@ -50,7 +50,6 @@ constexpr int TS = 256;       // tile rows / columns
 constexpr int SK = 32;        // k slab
 constexpr int LROW = 40;      // LDS row stride in halfs (80 bytes)
 constexpr int kThreads = 512;
-constexpr int kStagePerGroup = 2;  // V == 2: staging loads issued after each of the first groups
 
 // ---- max_k |a_ik| per row (bit pattern of a non-negative float: integer order = float order) -------
 __global__ __launch_bounds__(256) void RowAbsMaxKernel(const float* __restrict__ A, int64_t M, int64_t K,
@@ -187,11 +186,17 @@ struct SplitOperand {
 // are dealt round-robin over the 8 XCDs (b and b + 8 share one L2) and a CU holds one of them,
 // so the 32 that an XCD runs together are slots [32 r, 32 r + 32) of its own sequence: with the
 // permutation those are 4 x 8 neighbouring tiles - 12 operand panels for 32 tiles in that L2
-// instead of ~40 (every panel of the matrix).  The product is bound by the latency of its staging
-// loads (one slab in flight), and a load that hits the XCD's L2 returns in a third of the time.
-// V = 0: register-staged slabs (one in flight), padded LDS image, two barriers per slab.
-// V = 1: LDS-DMA staging (global_load_lds, no staging registers, no LDS write pass), two LDS
-// buffers, XOR-swizzled image, one barrier per slab.
+// instead of ~40 (every panel of the matrix).  Worth 1-4 % (measured, round 3).
+// Staging variants (EPSILON_HIP_GEMM_STAGE; measured on the Gram product of config 2, random
+// operands, counters in profiles/r03_gemm_split_pmc.txt):
+//   V = 3 "ring" (default): LDS-DMA into a ring of four 16-deep steps, the barrier in the middle
+//          of a step's matrix instructions: matrix pipe busy 87 % (the chip then holds 1.41 GHz:
+//          the product sits at the power limit, not at a stall), 11.8 ms;
+//   V = 1 "lds": LDS-DMA (global_load_lds: no staging registers, no LDS write pass), two
+//          32-deep buffers, one barrier per slab: busy 66 % at 1.7 GHz, 12.5 ms;
+//   V = 0 "reg": round 2 - register-staged slabs, padded LDS image (it was NOT conflict free:
+//          SQ_LDS_BANK_CONFLICT 6e8 against 0 for the swizzled images), two barriers per slab:
+//          busy 54 % at 1.8 GHz, 14.8 ms.
 template <int V>
 __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
     int64_t M, int64_t N, int64_t nslab, SplitOperand oa, SplitOperand ob, float alpha, float beta, float* C,
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if constexpr (V == 1) {
+    {
       for (int64_t ks = ks0; ks < ks1; ++ks) {
         if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);  // lands under this slab's MFMAs
 #pragma unroll
@@ -437,67 +442,6 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
         // barrier: a wave past it overwrites this buffer
         __builtin_amdgcn_sched_barrier(0);
         // the next slab has landed (this wave's pieces), every wave is done reading this one
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        cur ^= 1;
-      }
-    } else {
-      // V == 2: the same slab step with its issue order pinned.  All 24 fragment reads of the
-      // slab first (two register sets: the LDS latency is paid once per slab), then groups of
-      // four INDEPENDENT matrix instructions (one product term on the four accumulators of a
-      // pair of row blocks); the staging loads of the next slab go between the first groups, one
-      // or two per group, where their issue time hides behind the matrix pipe instead of in front
-      // of it.  The last iteration re-stages its own slab (a branch-free stream; 64 KB wasted per
-      // tile).
-      for (int64_t ks = ks0; ks < ks1; ++ks) {
-        const int64_t ksn = ks + 1 < ks1 ? ks + 1 : ks;
-        const _Float16* nb[4] = {oa.H + (ksn * oa.rows_pad + i0) * SK, oa.L + (ksn * oa.rows_pad + i0) * SK,
-                                 ob.H + (ksn * ob.rows_pad + j0) * SK, ob.L + (ksn * ob.rows_pad + j0) * SK};
-        half8 ih[2][4], il[2][4], jh[2][2], jl[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int seg = 2 * h + lh;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int off = offJ[b] + ((seg ^ swJ[b]) << 3);
-            jh[h][b] = *reinterpret_cast<const half8*>(&sm2[cur][2][off]);
-            jl[h][b] = *reinterpret_cast<const half8*>(&sm2[cur][3][off]);
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            const int off = offI[a] + ((seg ^ swI[a]) << 3);
-            ih[h][a] = *reinterpret_cast<const half8*>(&sm2[cur][0][off]);
-            il[h][a] = *reinterpret_cast<const half8*>(&sm2[cur][1][off]);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        int piece = 0;  // compile-time after unrolling
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int ap = 0; ap < 4; ap += 2)
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {
-#pragma unroll
-              for (int a = ap; a < ap + 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                  const half8 fj = term == 2 ? jl[h][b] : jh[h][b];
-                  const half8 fi = term == 1 ? il[h][a] : ih[h][a];
-                  acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fj, fi, acc[a][b], 0, 0, 0);
-                }
-#pragma unroll
-              for (int rep = 0; rep < kStagePerGroup; ++rep)
-                if (piece < 8) {
-                  const int arr = piece >> 1, q = piece & 1;
-                  __builtin_amdgcn_global_load_lds(
-                      (const __attribute__((address_space(1))) void*)(nb[arr] + src_off[q]),
-                      (__attribute__((address_space(3))) void*)(&sm2[cur ^ 1][arr][(wave_u * 2 + q) * 512]), 16, 0,
-                      0);
-                  ++piece;
-                }
-              __builtin_amdgcn_sched_barrier(0);
-            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
@@ -620,21 +564,26 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
 }
 
 // tail tiles: C tile = alpha * (sum of the S partial tiles, in order) / (s_i s_j) + beta * C
-__global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64_t lin0, int S,
+__global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64_t N, int64_t lin0, int S,
                                                                 const float* __restrict__ P,
-                                                                const unsigned* __restrict__ rowmax_bits,
+                                                                const unsigned* __restrict__ rowmax_i,
+                                                                const unsigned* __restrict__ rowmax_j,
                                                                 float alpha, float beta, float* C, int64_t ldc,
-                                                                const int* __restrict__ order) {
+                                                                const int* __restrict__ order, int lower) {
   const int64_t lin = lin0 + blockIdx.x;
   int64_t I, Jt;
   if (order != nullptr) {  // the tail tiles keep their place in the order table
     I = order[lin] >> 16;
     Jt = order[lin] & 0xffff;
-  } else {
+  } else if (lower) {
     I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
     while ((I + 1) * (I + 2) / 2 <= lin) ++I;
     while (I * (I + 1) / 2 > lin) --I;
     Jt = lin - I * (I + 1) / 2;
+  } else {
+    const int64_t TI = (M + TS - 1) / TS;
+    I = lin % TI;
+    Jt = lin / TI;
   }
   const int64_t i0 = I * TS, j0 = Jt * TS;
   const float* p0 = P + static_cast<int64_t>(blockIdx.x) * S * (TS * TS);
@@ -644,11 +593,11 @@ __global__ __launch_bounds__(256) void SyrkSplitTailFixupKernel(int64_t M, int64
   const int e_begin = static_cast<int>(blockIdx.y) * per;
   for (int e = e_begin + threadIdx.x; e < e_begin + per; e += 256) {
     const int64_t i = i0 + (e & (TS - 1)), j = j0 + (e >> 8);
-    if (i >= M || j >= M) continue;
+    if (i >= M || j >= N) continue;
     float sum = p0[e];
     for (int c = 1; c < S; ++c) sum += p0[static_cast<int64_t>(c) * (TS * TS) + e];
     float* dst = C + i + j * ldc;
-    const float v = alpha * ((SplitScaleInv(rowmax_bits[i]) * sum) * SplitScaleInv(rowmax_bits[j]));
+    const float v = alpha * ((SplitScaleInv(rowmax_i[i]) * sum) * SplitScaleInv(rowmax_j[j]));
     *dst = (beta == 0.0f) ? v : v + beta * (*dst);
   }
 }
@@ -669,7 +618,6 @@ int StageVariant() {
   if (e == nullptr) return 3;
   if (std::strcmp(e, "reg") == 0) return 0;  // register-staged, padded image (round 2)
   if (std::strcmp(e, "lds") == 0) return 1;  // LDS-DMA, two 32-deep buffers, compiler-scheduled
-  if (std::strcmp(e, "pin") == 0) return 2;  // the same with its issue order pinned
   return 3;                                   // "ring": four 16-deep steps
 }
 bool PatchOrderEnabled() {
@@ -717,9 +665,6 @@ void LaunchSplit(dim3 grid, int64_t M, int64_t N, int64_t nslab, const SplitOper
   const int v = StageVariant();
   if (v == 3)
     hipLaunchKernelGGL(GemmSplitF16Kernel<3>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
-                       lin0, slab0, slab_count, P, order, perm_limit);
-  else if (v == 2)
-    hipLaunchKernelGGL(GemmSplitF16Kernel<2>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
                        lin0, slab0, slab_count, P, order, perm_limit);
   else if (v == 1)
     hipLaunchKernelGGL(GemmSplitF16Kernel<1>, grid, dim3(kThreads), 0, s, M, N, nslab, oa, ob, al, be, C, ldc, tri,
@@ -801,22 +746,16 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
   const int64_t TI = (M + TS - 1) / TS, TJ = (N + TS - 1) / TS;
   int64_t ocount = 0;
   const int* order = PatchOrderEnabled() ? TileOrder(TI, TJ, lower_only, &ocount) : nullptr;
-  if (!lower_only) {
-    EPS_CHECK(order == nullptr || ocount == TI * TJ);
-    LaunchSplit(dim3(static_cast<unsigned>(TI * TJ)), M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, 0, 0, 0, nslab,
-                nullptr, order, TI * TJ / 256 * 256);
-    EPS_HIP(hipGetLastError());
-    return true;
-  }
-  const int64_t total = TI * (TI + 1) / 2;
+  const int64_t total = lower_only ? TI * (TI + 1) / 2 : TI * TJ;
+  const int tri = lower_only ? 1 : 0;
   EPS_CHECK(order == nullptr || ocount == total);
   // one 512-thread workgroup per CU: rounds of 256 tiles; a ragged last round of a LONG
-  // contraction is split over K
+  // contraction is split over K (raw partial tiles, summed in order by the fix-up kernel)
   const int64_t slots = 256;
   int64_t tail = total % slots;
   int S = 1;
   int64_t per = nslab;
-  if (same && nslab >= 64 && total > slots && tail > 0 && tail <= slots / 2) {
+  if (nslab >= 64 && total > slots && tail > 0 && tail <= slots / 2) {
     S = static_cast<int>(std::min<int64_t>(8, slots / tail));
     per = (nslab + S - 1) / S;
     S = static_cast<int>((nslab + per - 1) / per);
@@ -825,15 +764,15 @@ bool GemmSplitF16(bool transA, bool transB, int64_t M, int64_t N, int64_t K, dou
   }
   const int64_t full = total - tail;
   if (full > 0)
-    LaunchSplit(dim3(static_cast<unsigned>(full)), M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, 1, 0, 0, nslab,
+    LaunchSplit(dim3(static_cast<unsigned>(full)), M, N, nslab, oa, ob, al, be, C.as<float>(), ldc, tri, 0, 0, nslab,
                 nullptr, order, full / 256 * 256);
   if (tail > 0) {
     auto pbuf = rt.Alloc(static_cast<size_t>(tail) * S * TS * TS * sizeof(float));
     float* P = static_cast<float*>(pbuf->p);
     LaunchSplit(dim3(static_cast<unsigned>(tail), static_cast<unsigned>(S)), M, N, nslab, oa, ob, al, be,
-                C.as<float>(), ldc, 1, full, 0, per, P, order, 0);
-    hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail), 16), dim3(256), 0, s, M, full, S,
-                       P, oa.rowmax, al, be, C.as<float>(), ldc, order);
+                C.as<float>(), ldc, tri, full, 0, per, P, order, 0);
+    hipLaunchKernelGGL(SyrkSplitTailFixupKernel, dim3(static_cast<unsigned>(tail), 16), dim3(256), 0, s, M, N, full,
+                       S, P, oa.rowmax, ob.rowmax, al, be, C.as<float>(), ldc, order, tri);
   }
   EPS_HIP(hipGetLastError());
   return true;

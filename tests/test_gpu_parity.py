@@ -315,6 +315,47 @@ def test_gemm_f16_split_general_and_inverse(solve_mod):
     assert np.array_equal(W, W.T)
 
 
+def test_gemm_f16_split_general_tail_tiles(solve_mod):
+    """A general product with more tiles than CUs and a long contraction: the ragged last round of
+    tiles is split over K (raw partial tiles + the fix-up kernel, two different operands and row
+    scale arrays), in patch order and in plain order, with every staging variant of the kernel."""
+    import os
+    solve_mod.set_option("dtype", "f32")
+    rng = np.random.RandomState(29)
+    m, k, n = 4300, 2100, 4400  # 17 x 18 = 306 tiles: 256 + a tail of 50 split 5 ways
+    A = (rng.randn(m, k) * np.exp(rng.uniform(-3, 3, size=(m, 1)))).astype(np.float32).astype(np.float64)
+    B = (rng.randn(k, n) * np.exp(rng.uniform(-3, 3, size=(1, n)))).astype(np.float32).astype(np.float64)
+    ref = A.dot(B)
+    scale = np.outer(np.linalg.norm(A, axis=1), np.linalg.norm(B, axis=0))
+    results = {}
+    saved = {v: os.environ.get(v) for v in ("EPSILON_HIP_GEMM_STAGE", "EPSILON_HIP_GEMM_ORDER")}
+    try:
+        for stage, order in (("ring", "1"), ("ring", "0"), ("lds", "1"), ("reg", "1")):
+            os.environ["EPSILON_HIP_GEMM_STAGE"] = stage
+            os.environ["EPSILON_HIP_GEMM_ORDER"] = order
+            solve_mod.profile_enable(True)
+            solve_mod.profile_reset()
+            _, C = solve_mod.linear_map_binary("*", ir.dense_matrix(A), ir.dense_matrix(B), False, False)
+            tags = solve_mod.profile_dump()
+            solve_mod.profile_enable(False)
+            assert any(t.startswith("gemm_f16split") for t in tags), list(tags)
+            err = np.abs(C - ref) / scale
+            assert err.max() < 4 * np.sqrt(k) * 2.0 ** -24, (stage, order, err.max())
+            results[(stage, order)] = C
+    finally:
+        for v, old in saved.items():
+            if old is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = old
+    # the same multiply-adds in the same order whatever the staging (the tile order decides WHICH
+    # tiles form the ragged round and are summed in K chunks, so it may change their last bits)
+    first = results[("ring", "1")]
+    for key, C in results.items():
+        if key[1] == "1":
+            assert np.array_equal(C, first), key
+
+
 @pytest.mark.parametrize("mode", ["mfma", "mfma_simple", "auto"])
 def test_gemm_f64_mfma_vs_numpy(solve_mod, mode):
     """Dense*Dense in fp64 on v_mfma_f64_16x16x4_f64 (its accumulator map is NOT the f32 one): all
