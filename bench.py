@@ -309,7 +309,7 @@ def main():
         if args.comm == "rccl":
             _solve.comm_warmup(25 * (1 << 20))
         if args.peer == "auto":
-            peer_on, peer_why = _solve.comm_enable_peer(max(m, 16384), args.rehearse_ranks)
+            peer_on, peer_why = _solve.comm_enable_peer(max(m * (2 if args.dtype == "f64" else 1), 16384), args.rehearse_ranks)
         else:
             peer_on, peer_why = False, "--peer off"
         comm_used = ("one-shot xGMI peer-write window inside the sweep kernels + hipGraph replay; "
@@ -369,7 +369,7 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=device if args.comm == "rccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
-            peer_on, _ = _solve.comm_enable_peer(max(m, 16384), 0)
+            peer_on, _ = _solve.comm_enable_peer(max(m * (2 if args.dtype == "f64" else 1), 16384), 0)
         else:
             peer_on = False
         if not peer_on:

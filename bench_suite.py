@@ -91,7 +91,41 @@ def mnist_hinge_features():
     return _hinge(60000, 4000, 10, 10.0, 196.57, 30, "docs/notebooks/mnist.rst:238-244")
 
 
-SUITE = [("lasso", lasso), ("tv_1d", tv_1d), ("robust_pca", robust_pca), ("mnist_hinge", mnist_hinge),
+def mv_lasso():
+    from epsilon_amd import problems
+    n, k = 5000, 10
+    prob, info = problems.mv_lasso(1500, n, k, rho=0.01, seed=0)
+    return prob, lambda x: problems.mv_lasso_objective(info["A"], info["B"], info["lam"],
+                                                       x["var:X"].reshape(n, k, order="F")), \
+        dict(ref_total_s=7.14, ref_objective=4.87e2, size="m=1500 n=5000 k=10, X0 density 0.01 (Kronecker data map)",
+             ref_source="docs/_static/benchmarks.png (benchmark.py:46)")
+
+
+def fused_lasso():
+    from epsilon_amd import problems
+    prob, info = problems.fused_lasso(1000, 10, 1000, seed=0)
+    return prob, lambda x: problems.fused_lasso_objective(info["A"], info["b"], info["lam"], x["var:x"]), \
+        dict(ref_total_s=3.87, ref_objective=7.46e1, size="m=1000, ni=10, k=1000 (least squares + l1 + total variation)",
+             ref_source="docs/_static/benchmarks.png (benchmark.py:30)")
+
+
+def mnist():
+    """The reference's "mnist" row: a lasso-style fit of one-hot labels on 1000 random features of
+    its own 2000-sample mnist_small data (tests/golden/mnist_small.npz: the arrays of the
+    reference's data file, re-packed)."""
+    from epsilon_amd import problems
+    d = np.load(os.path.join(ROOT, "tests", "golden", "mnist_small.npz"))
+    n, k = 1000, 10
+    prob, info = problems.mnist_features_lasso(d["X"], d["y"], n=n, lam=0.1, seed=0)
+    return prob, lambda x: problems.mv_lasso_objective(info["A"], info["B"], info["lam"],
+                                                       x["var:X"].reshape(n, k, order="F")), \
+        dict(ref_total_s=0.91, ref_objective=1.75e3, size="2000 samples x 1000 random features, k=10, lam=0.1",
+             ref_source="docs/_static/benchmarks.png (benchmark.py:45, problems/mnist.py:51-64)",
+             data="the reference's mnist_small arrays")
+
+
+SUITE = [("lasso", lasso), ("mv_lasso", mv_lasso), ("fused_lasso", fused_lasso), ("tv_1d", tv_1d),
+         ("robust_pca", robust_pca), ("mnist", mnist), ("mnist_hinge", mnist_hinge),
          ("mnist_hinge_features", mnist_hinge_features), ("lasso_sparse", lasso_sparse)]
 
 
@@ -118,7 +152,7 @@ def main():
         xs = {k: np.frombuffer(v) for k, v in x.items()}
         out = {"problem": name, "solve_s": t_solve, "init_s": S.timing.init_time, "loop_s": S.timing.total_time - S.timing.init_time,
                "iterations": S.num_iterations + 1, "state": STATES[S.state], "objective": objective(xs),
-               "dtype": "f32", "data": "synthetic", "host_blob_bytes": sum(len(v) for v in data.values()),
+               "dtype": "f32", "data": ref.pop("data", "synthetic"), "host_blob_bytes": sum(len(v) for v in data.values()),
                "ir_build_s": t_build, "reference": ref}
         print(json.dumps(out), flush=True)
 

@@ -367,7 +367,8 @@ class ProxADMMSolver final : public Solver {
       const bool sharded = sh.active() && sh.IsSharded(f.ls.var_key);
       // one-shot peer-write exchange inside the sweep's own kernels (kernels_peer.hip) when the
       // ranks share a window and the m-float message fits its slots; RCCL collectives otherwise
-      f.use_peer = dt == F32 && sharded && px != nullptr && f.m <= px->slot() && f.ls.Dinv_arg != nullptr &&
+      // (a granule carries 32 value bits: an f64 value takes two)
+      f.use_peer = sharded && px != nullptr && f.m * (dt == F64 ? 2 : 1) <= px->slot() && f.ls.Dinv_arg != nullptr &&
                    !f.ls.Dinv_arg->trans() && f.ls.Dinv_arg->rows() == f.m;
       const int G = f.use_peer ? px->view().G : (comm ? comm->size() : 1);
       f.slab = ((f.m + G - 1) / G + 3) / 4 * 4;

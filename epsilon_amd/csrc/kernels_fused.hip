@@ -144,8 +144,10 @@ template <int NR, int BS, int MODE>
 __global__ __launch_bounds__(BS, 2) void LassoFusedStreamKernelF64(
     int64_t m, int64_t n, const double* __restrict__ A, int64_t lda, const double* __restrict__ w,
     FusedScalarsT<double> c, double* u, double* x0, double* x1, double* y0, double* y1,
-    double* y1prev, double* __restrict__ tpart, double* e0, double* e1) {
+    double* y1prev, double* __restrict__ tpart, unsigned* epoch, double* e0, double* e1) {
   __shared__ double red[2][BS / 64];
+  // the exchange kernels behind this pass tag their granules with the sweep number
+  if (epoch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *epoch += 1u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double2 wv[NR], tp[NR];
   int64_t row[NR];
@@ -687,7 +689,6 @@ namespace {
 void LassoFusedPassF64(const LassoFusedArgs& a, int grid, int block) {
   FusedScalarsT<double> c{a.kappa, a.Bs, a.Cs, a.a1, a.lam, a.sz_alpha, a.sz_beta, a.sz_M,
                           a.a0, 1.0 / (a.a0 * a.a0 + a.a1 * a.a1), nullptr, nullptr};
-  EPS_CHECK_MSG(a.epoch == nullptr, "the peer exchange is f32 only");
   if (a.sz_alpha_vec.n > 0) {
     EPS_CHECK(a.sz_alpha_vec.n == a.n && a.sz_alpha_vec.dt == F64);
     c.alpha_v = a.sz_alpha_vec.as<double>();
@@ -708,12 +709,12 @@ void LassoFusedPassF64(const LassoFusedArgs& a, int grid, int block) {
       hipLaunchKernelGGL((LassoFusedStreamKernelF64<NRV, BSV, 1>), dim3(grid), dim3(BSV), 0, s, a.m, a.n, \
                          a.A.as<double>(), a.lda, a.w.as<double>(), c, a.u.as<double>(),                  \
                          a.x0.as<double>(), a.x1.as<double>(), a.y0.as<double>(), a.y1.as<double>(),      \
-                         a.y1prev.as<double>(), a.tpart.as<double>(), e0, e1);                            \
+                         a.y1prev.as<double>(), a.tpart.as<double>(), a.epoch, e0, e1);                   \
     else                                                                                                  \
       hipLaunchKernelGGL((LassoFusedStreamKernelF64<NRV, BSV, 0>), dim3(grid), dim3(BSV), 0, s, a.m, a.n, \
                          a.A.as<double>(), a.lda, a.w.as<double>(), c, a.u.as<double>(),                  \
                          a.x0.as<double>(), a.x1.as<double>(), a.y0.as<double>(), a.y1.as<double>(),      \
-                         a.y1prev.as<double>(), a.tpart.as<double>(), e0, e1);                            \
+                         a.y1prev.as<double>(), a.tpart.as<double>(), a.epoch, e0, e1);                   \
   } while (0)
   if (block == 256) {
     if (need <= 1) EPS_FUSED_CASE64(1, 256);

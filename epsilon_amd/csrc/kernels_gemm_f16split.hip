@@ -651,7 +651,11 @@ const int* TileOrder(int64_t TI, int64_t TJ, bool lower, int64_t* count) {
     Entry e;
     e.count = static_cast<int64_t>(h.size());
     e.buf = Runtime::Get().Alloc(h.size() * sizeof(int));
-    EPS_HIP(hipMemcpy(e.buf->p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+    // on the library's own stream (the legacy default stream may not exist yet in this process,
+    // and creating it costs tens of milliseconds); once per shape, so the wait is affordable
+    hipStream_t st = Runtime::Get().stream();
+    EPS_HIP(hipMemcpyAsync(e.buf->p, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    EPS_HIP(hipStreamSynchronize(st));
     it = cache->emplace(key, std::move(e)).first;
   }
   *count = it->second.count;

@@ -47,8 +47,8 @@ constexpr unsigned long long kTimeoutTicks = 200000000ull;  // 2 s at 100 MHz
 
 typedef unsigned long long u64;
 
-__device__ inline u64 Granule(unsigned tag, float v) {
-  return (static_cast<u64>(tag) << 32) | static_cast<u64>(__float_as_uint(v));
+__device__ inline u64 Granule(unsigned tag, unsigned bits) {
+  return (static_cast<u64>(tag) << 32) | static_cast<u64>(bits);
 }
 
 __device__ inline void PushGranule(u64* dst, u64 g) {
@@ -80,24 +80,72 @@ __device__ inline u64* Slot(const PeerView& pv, int dest, int channel, unsigned 
          ((static_cast<long long>(channel) * 2 + (epoch & 1u)) * pv.G + source) * pv.slot + i;
 }
 
-__device__ inline bool PollOne(const PeerView& pv, int channel, unsigned epoch, int source,
-                               long long i, unsigned tag, float* val, unsigned code) {
+__device__ inline bool PollBits(const PeerView& pv, int channel, unsigned epoch, int source,
+                                long long i, unsigned tag, unsigned* bits, unsigned code) {
   const u64 t0 = wall_clock64();
   const u64* g = Slot(pv, pv.rank, channel, epoch, source, i);
   for (;;) {
     const u64 x = LoadGranule(g);
     if (static_cast<unsigned>(x >> 32) == tag) {
-      *val = __uint_as_float(static_cast<unsigned>(x));
+      *bits = static_cast<unsigned>(x);
       return true;
     }
     if (Failed(pv) || wall_clock64() - t0 > kTimeoutTicks) {
       ReportTimeout(pv, code);
-      *val = 0.0f;
+      *bits = 0u;
       return false;
     }
     __builtin_amdgcn_s_sleep(4);
   }
 }
+
+// One value of the exchanged vectors: an f32 value is ONE granule (index i of its slot), an f64
+// value TWO - {tag, high word} at 2 i and {tag, low word} at 2 i + 1, each its own flag - so a
+// window slot of S granules carries S floats or S / 2 doubles.
+template <class T> struct PeerVal;
+template <> struct PeerVal<float> {
+  static constexpr int kGran = 1;
+  __device__ static void Push(const PeerView& pv, int dest, int channel, unsigned epoch, int source, long long i,
+                              unsigned tag, float v) {
+    PushGranule(Slot(pv, dest, channel, epoch, source, i), Granule(tag, __float_as_uint(v)));
+  }
+  __device__ static float Poll(const PeerView& pv, int channel, unsigned epoch, int source, long long i,
+                               unsigned tag, unsigned code) {
+    unsigned b;
+    PollBits(pv, channel, epoch, source, i, tag, &b, code);
+    return __uint_as_float(b);
+  }
+};
+template <> struct PeerVal<double> {
+  static constexpr int kGran = 2;
+  __device__ static void Push(const PeerView& pv, int dest, int channel, unsigned epoch, int source, long long i,
+                              unsigned tag, double v) {
+    const u64 b = static_cast<u64>(__double_as_longlong(v));
+    PushGranule(Slot(pv, dest, channel, epoch, source, 2 * i), Granule(tag, static_cast<unsigned>(b >> 32)));
+    PushGranule(Slot(pv, dest, channel, epoch, source, 2 * i + 1), Granule(tag, static_cast<unsigned>(b)));
+  }
+  __device__ static double Poll(const PeerView& pv, int channel, unsigned epoch, int source, long long i,
+                                unsigned tag, unsigned code) {
+    unsigned hi, lo;
+    PollBits(pv, channel, epoch, source, 2 * i, tag, &hi, code);
+    PollBits(pv, channel, epoch, source, 2 * i + 1, tag, &lo, code);
+    return __longlong_as_double(static_cast<long long>((static_cast<u64>(hi) << 32) | lo));
+  }
+};
+
+// four consecutive entries of a vector: one 16-byte load in f32, two in f64
+template <class T> struct Quad {
+  T x, y, z, w;
+};
+__device__ inline Quad<float> LoadQuad(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return Quad<float>{v.x, v.y, v.z, v.w};
+}
+__device__ inline Quad<double> LoadQuad(const double* p) {
+  const double2 a = *reinterpret_cast<const double2*>(p), b = *reinterpret_cast<const double2*>(p + 2);
+  return Quad<double>{a.x, a.y, b.x, b.y};
+}
+template <class T> __device__ inline Quad<T> ZeroQuad() { return Quad<T>{T(0), T(0), T(0), T(0)}; }
 
 __global__ void PeerBumpEpochKernel(PeerView pv) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *pv.epoch += 1u;
@@ -113,21 +161,21 @@ __global__ void PeerBumpEpochKernel(PeerView pv) {
 constexpr int kRQ = 8;                 // row quads per workgroup (32 rows)
 constexpr int kPL = kBlock / kRQ;      // 32 part lanes
 
+template <class T>
 __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
-    PeerView pv, long long rows, int nparts, const float* __restrict__ partial, float alpha,
-    const float* __restrict__ add, float* __restrict__ y) {
-  __shared__ float4 part[kBlock / 64][kRQ];
+    PeerView pv, long long rows, int nparts, const T* __restrict__ partial, T alpha,
+    const T* __restrict__ add, T* __restrict__ y) {
+  __shared__ Quad<T> part[kBlock / 64][kRQ];
   const int t = threadIdx.x, rq = t & (kRQ - 1), pl = t >> 3, wave = t >> 6;
   const long long r0 = (static_cast<long long>(blockIdx.x) * kRQ + rq) * 4;  // rows % 4 == 0
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  Quad<T> s = ZeroQuad<T>();
   if (r0 < rows) {
-    const float* p = partial + r0;
+    const T* p = partial + r0;
     int k = pl;
     for (; k + 7 * kPL < nparts; k += 8 * kPL) {
-      float4 v[8];
+      Quad<T> v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        v[u] = *reinterpret_cast<const float4*>(p + static_cast<long long>(k + u * kPL) * rows);
+      for (int u = 0; u < 8; ++u) v[u] = LoadQuad(p + static_cast<long long>(k + u * kPL) * rows);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         s.x += v[u].x;
@@ -137,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
       }
     }
     for (; k < nparts; k += kPL) {
-      const float4 v = *reinterpret_cast<const float4*>(p + static_cast<long long>(k) * rows);
+      const Quad<T> v = LoadQuad(p + static_cast<long long>(k) * rows);
       s.x += v.x;
       s.y += v.y;
       s.z += v.z;
@@ -155,19 +203,19 @@ __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
   if ((t & 63) < kRQ) part[wave][rq] = s;
   __syncthreads();
   // The exchange is spread over the whole workgroup: thread (row, q) = (t & 31, t >> 5) pushes ONE
-  // granule to peer q and polls ONE granule of source q - one store and one load per lane and
+  // value to peer q and polls ONE value of source q - one or two stores and loads per lane and
   // round instead of 32 of each on 8 lanes (the kernel is latency-bound, not bandwidth-bound).
   static_assert(kRQ * 4 * PeerView::kMaxPeers == kBlock, "one (row, peer) pair per thread");
-  __shared__ float mine_s[kRQ * 4];
-  __shared__ float got[PeerView::kMaxPeers][kRQ * 4];
+  __shared__ T mine_s[kRQ * 4];
+  __shared__ T got[PeerView::kMaxPeers][kRQ * 4];
   const long long rbase = static_cast<long long>(blockIdx.x) * kRQ * 4;
   if (t < kRQ * 4) {
-    const float4 a = part[0][t >> 2], b = part[1][t >> 2], c = part[2][t >> 2], d = part[3][t >> 2];
+    const Quad<T> a = part[0][t >> 2], b = part[1][t >> 2], c = part[2][t >> 2], d = part[3][t >> 2];
     const int e = t & 3;
-    const float av = e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w;
-    const float bv = e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w;
-    const float cv = e == 0 ? c.x : e == 1 ? c.y : e == 2 ? c.z : c.w;
-    const float dv = e == 0 ? d.x : e == 1 ? d.y : e == 2 ? d.z : d.w;
+    const T av = e == 0 ? a.x : e == 1 ? a.y : e == 2 ? a.z : a.w;
+    const T bv = e == 0 ? b.x : e == 1 ? b.y : e == 2 ? b.z : b.w;
+    const T cv = e == 0 ? c.x : e == 1 ? c.y : e == 2 ? c.z : c.w;
+    const T dv = e == 0 ? d.x : e == 1 ? d.y : e == 2 ? d.z : d.w;
     mine_s[t] = alpha * (((av + bv) + cv) + dv);
   }
   __syncthreads();
@@ -177,15 +225,13 @@ __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
     const int row = t & (kRQ * 4 - 1), q = t >> 5;  // kRQ * 4 == 32
     const long long r = rbase + row;
     if (q < pv.G && r < rows) {
-      PushGranule(Slot(pv, q, 0, epoch, pv.rehearse ? q : pv.rank, r), Granule(tag, mine_s[row]));
-      float v;
-      PollOne(pv, 0, epoch, q, r, tag, &v, 1u);
-      got[q][row] = v;
+      PeerVal<T>::Push(pv, q, 0, epoch, pv.rehearse ? q : pv.rank, r, tag, mine_s[row]);
+      got[q][row] = PeerVal<T>::Poll(pv, 0, epoch, q, r, tag, 1u);
     }
   }
   __syncthreads();
   if (t < kRQ * 4 && rbase + t < rows) {
-    float acc = got[0][t];
+    T acc = got[0][t];
     for (int q = 1; q < pv.G; ++q) acc += got[q][t];
     if (add) acc += add[rbase + t];
     y[rbase + t] = acc;
@@ -197,14 +243,14 @@ __global__ __launch_bounds__(kBlock) void PeerReduceExchangeKernel(
 // CP columns per workgroup pass, the CP dot products reduced by wave shuffles and across the 4
 // waves in a fixed order (GemvT2Kernel's scheme); the lanes that hold the results push them.  Afterwards every thread gathers a share of the G*slab granules of
 // w from the local window into the plain vector the streaming pass reads.
-template <int CP>
+template <int CP, class T>
 __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
-    PeerView pv, long long m, long long slab, long long lo, const float* __restrict__ D,
-    long long ldd, float scale, const float* __restrict__ p, float* __restrict__ wpad) {
+    PeerView pv, long long m, long long slab, long long lo, const T* __restrict__ D,
+    long long ldd, T scale, const T* __restrict__ p, T* __restrict__ wpad) {
   // (p is read straight from global memory: a thread only ever needs the entries of its own row
   // chunks, nothing is shared between threads, and a workgroup takes one or two passes - staging
-  // the m floats in LDS first cost a third of the kernel's traffic)
-  __shared__ float red[kBlock / 64][CP];
+  // the m values in LDS first cost a third of the kernel's traffic)
+  __shared__ T red[kBlock / 64][CP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned epoch = *pv.epoch;
   const unsigned tag = 2u * epoch + 2u;
@@ -212,13 +258,15 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
   const long long nvec = m / 4;
   for (long long pass = blockIdx.x; pass < npass; pass += gridDim.x) {
     const long long j0 = pass * CP;
-    float acc[CP];
+    T acc[CP];
 #pragma unroll
-    for (int c = 0; c < CP; ++c) acc[c] = 0.0f;
-    // RU row chunks x CP columns = 8 independent 16-byte loads per thread and step
-    constexpr int RU = 8 / CP;
+    for (int c = 0; c < CP; ++c) acc[c] = T(0);
+    // RU row chunks x CP columns = 8 independent loads of four entries per thread and step (f32;
+    // half as many chunks in f64, where a chunk is two 16-byte loads)
+    constexpr int RU = (sizeof(T) == 4 ? 8 : 4) / CP;
+    static_assert(RU >= 1, "columns per pass");
     bool live[CP];
-    const float* colp[CP];
+    const T* colp[CP];
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
       const long long col = lo + j0 + c;
@@ -226,16 +274,14 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
       colp[c] = D + (live[c] ? col : 0) * ldd;
     }
     for (long long q0 = threadIdx.x; q0 < nvec; q0 += kBlock * RU) {
-      float4 a[RU][CP], xv[RU];
+      Quad<T> a[RU][CP], xv[RU];
 #pragma unroll
       for (int r = 0; r < RU; ++r) {
         const long long q = q0 + static_cast<long long>(r) * kBlock;
         const bool in = q < nvec;
 #pragma unroll
-        for (int c = 0; c < CP; ++c)
-          a[r][c] = (in && live[c]) ? *reinterpret_cast<const float4*>(colp[c] + q * 4)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-        xv[r] = in ? reinterpret_cast<const float4*>(p)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < CP; ++c) a[r][c] = (in && live[c]) ? LoadQuad(colp[c] + q * 4) : ZeroQuad<T>();
+        xv[r] = in ? LoadQuad(p + q * 4) : ZeroQuad<T>();
       }
 #pragma unroll
       for (int r = 0; r < RU; ++r) {
@@ -250,18 +296,18 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
     }
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      float v = acc[c];
+      T v = acc[c];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
       if (lane == 0) red[wave][c] = v;
     }
     __syncthreads();
-    // thread (c, q) pushes column c's result to peer q: one store per lane
+    // thread (c, q) pushes column c's result to peer q: one value per lane
     if (threadIdx.x < CP * PeerView::kMaxPeers) {
       const int c = threadIdx.x % CP, q = threadIdx.x / CP;
       if (j0 + c < slab && q < pv.G) {
-        const float t = scale * (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
-        PushGranule(Slot(pv, q, 1, epoch, pv.rehearse ? q : pv.rank, j0 + c), Granule(tag, t));
+        const T t = scale * (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+        PeerVal<T>::Push(pv, q, 1, epoch, pv.rehearse ? q : pv.rank, j0 + c, tag, t);
         // the own slab goes straight into w: no workgroup of this grid ever waits for another
         // workgroup of the same grid, only for other GPUs
         if (q == 0 && !pv.rehearse) wpad[static_cast<long long>(pv.rank) * slab + j0 + c] = t;
@@ -269,16 +315,14 @@ __global__ __launch_bounds__(kBlock) void PeerSlabApplyExchangeKernel(
     }
     __syncthreads();
   }
-  // gather the other ranks' slabs: granule g = q*slab + j of channel 1
+  // gather the other ranks' slabs: value g = q*slab + j of channel 1
   const long long total = static_cast<long long>(pv.G) * slab;
   for (long long g = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; g < total;
        g += static_cast<long long>(gridDim.x) * kBlock) {
     const int q = static_cast<int>(g / slab);
     if (q == pv.rank && !pv.rehearse) continue;
     const long long j = g - q * slab;
-    float v;
-    PollOne(pv, 1, epoch, q, j, tag, &v, 2u);
-    wpad[g] = v;
+    wpad[g] = PeerVal<T>::Poll(pv, 1, epoch, q, j, tag, 2u);
   }
 }
 
@@ -289,38 +333,47 @@ void PeerBumpEpoch(const PeerView& pv) {
   EPS_HIP(hipGetLastError());
 }
 
+// granules per value: a window slot of pv.slot granules carries pv.slot floats or half as many doubles
+static int64_t GranulesPerValue(DType dt) { return dt == F64 ? 2 : 1; }
+
 void PeerReduceExchange(const PeerView& pv, int64_t rows, int nparts, const DVec& partial,
                         double alpha, const DVec* add, const DVec& y) {
-  EPS_CHECK(partial.dt == F32 && y.dt == F32 && y.n == rows);
+  const DType dt = partial.dt;
+  EPS_CHECK(y.dt == dt && y.n == rows);
   EPS_CHECK(partial.n >= static_cast<int64_t>(nparts) * rows && nparts >= 1);
-  EPS_CHECK_MSG(rows <= pv.slot, "peer exchange: " << rows << " rows exceed the window slot of "
-                                                   << pv.slot);
-  if (add) EPS_CHECK(add->n == rows && add->dt == F32);
+  EPS_CHECK_MSG(rows * GranulesPerValue(dt) <= pv.slot,
+                "peer exchange: " << rows << " rows exceed the window slot of " << pv.slot << " granules");
+  if (add) EPS_CHECK(add->n == rows && add->dt == dt);
   if (rows == 0) return;
   ProfScope prof("peer_reduce_exchange", rows, nparts);
   EPS_CHECK_MSG(rows % 4 == 0 && reinterpret_cast<uintptr_t>(partial.data()) % 16 == 0 &&
                     reinterpret_cast<uintptr_t>(y.data()) % 16 == 0,
                 "peer exchange: rows must be a multiple of 4 and the buffers 16-byte aligned");
   const unsigned grid = static_cast<unsigned>((rows / 4 + kRQ - 1) / kRQ);
-  hipLaunchKernelGGL(PeerReduceExchangeKernel, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(),
-                     pv, static_cast<long long>(rows), nparts, partial.as<float>(),
-                     static_cast<float>(alpha), add ? add->as<float>() : nullptr, y.as<float>());
+  if (dt == F32)
+    hipLaunchKernelGGL(PeerReduceExchangeKernel<float>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), pv,
+                       static_cast<long long>(rows), nparts, partial.as<float>(), static_cast<float>(alpha),
+                       add ? add->as<float>() : nullptr, y.as<float>());
+  else
+    hipLaunchKernelGGL(PeerReduceExchangeKernel<double>, dim3(grid), dim3(kBlock), 0, Runtime::Get().stream(), pv,
+                       static_cast<long long>(rows), nparts, partial.as<double>(), alpha,
+                       add ? add->as<double>() : nullptr, y.as<double>());
   EPS_HIP(hipGetLastError());
 }
 
 bool PeerSlabApplySupported(const PeerView& pv, int64_t m, int64_t slab, const DVec& D, int64_t ldd) {
-  return D.dt == F32 && m % 4 == 0 && ldd % 4 == 0 && slab <= pv.slot &&
+  return m % 4 == 0 && ldd % 4 == 0 && slab * GranulesPerValue(D.dt) <= pv.slot &&
          reinterpret_cast<uintptr_t>(D.data()) % 16 == 0;
 }
 
 void PeerSlabApplyExchange(const PeerView& pv, int64_t m, int64_t slab, int64_t lo, const DVec& D,
                            int64_t ldd, double scale, const DVec& p, const DVec& wpad) {
   EPS_CHECK(PeerSlabApplySupported(pv, m, slab, D, ldd));
-  EPS_CHECK(p.n == m && p.dt == F32 && wpad.dt == F32 && wpad.n >= slab * pv.G);
+  const DType dt = D.dt;
+  EPS_CHECK(p.n == m && p.dt == dt && wpad.dt == dt && wpad.n >= slab * pv.G);
   EPS_CHECK(D.n >= (m - 1) * ldd + m && lo >= 0);
   EPS_CHECK(reinterpret_cast<uintptr_t>(p.data()) % 16 == 0);
   ProfScope prof("peer_slab_apply_exchange", m, slab);
-  const size_t lds = 0;
   hipStream_t s = Runtime::Get().stream();
   // enough workgroups to fill the chip twice over: 4 columns per pass while that gives >= 512
   // passes, 2 below (at m = 1e4 and 8 ranks: 626 passes of 2 columns)
@@ -331,16 +384,23 @@ void PeerSlabApplyExchange(const PeerView& pv, int64_t m, int64_t slab, int64_t 
   // chip (ranks that share one GPU in the tests need room to run beside each other)
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
-  if (wide)
-    hipLaunchKernelGGL(PeerSlabApplyExchangeKernel<4>, dim3(static_cast<unsigned>(grid)), dim3(kBlock),
-                       lds, s, pv, static_cast<long long>(m), static_cast<long long>(slab),
-                       static_cast<long long>(lo), D.as<float>(), static_cast<long long>(ldd),
-                       static_cast<float>(scale), p.as<float>(), wpad.as<float>());
-  else
-    hipLaunchKernelGGL(PeerSlabApplyExchangeKernel<2>, dim3(static_cast<unsigned>(grid)), dim3(kBlock),
-                       lds, s, pv, static_cast<long long>(m), static_cast<long long>(slab),
-                       static_cast<long long>(lo), D.as<float>(), static_cast<long long>(ldd),
-                       static_cast<float>(scale), p.as<float>(), wpad.as<float>());
+  const dim3 g(static_cast<unsigned>(grid)), b(kBlock);
+  const long long mm = m, sl = slab, l0 = lo, ld = ldd;
+  if (dt == F32) {
+    if (wide)
+      hipLaunchKernelGGL((PeerSlabApplyExchangeKernel<4, float>), g, b, 0, s, pv, mm, sl, l0, D.as<float>(), ld,
+                         static_cast<float>(scale), p.as<float>(), wpad.as<float>());
+    else
+      hipLaunchKernelGGL((PeerSlabApplyExchangeKernel<2, float>), g, b, 0, s, pv, mm, sl, l0, D.as<float>(), ld,
+                         static_cast<float>(scale), p.as<float>(), wpad.as<float>());
+  } else {
+    if (wide)
+      hipLaunchKernelGGL((PeerSlabApplyExchangeKernel<4, double>), g, b, 0, s, pv, mm, sl, l0, D.as<double>(), ld,
+                         scale, p.as<double>(), wpad.as<double>());
+    else
+      hipLaunchKernelGGL((PeerSlabApplyExchangeKernel<2, double>), g, b, 0, s, pv, mm, sl, l0, D.as<double>(), ld,
+                         scale, p.as<double>(), wpad.as<double>());
+  }
   EPS_HIP(hipGetLastError());
 }
 

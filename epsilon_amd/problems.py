@@ -254,6 +254,107 @@ def group_lasso_objective(A, B, lam, X):
     return float(np.sum((A.dot(X) - B) ** 2) + lam * np.sqrt((X ** 2).sum(axis=1)).sum())
 
 
+def mv_lasso_ir(A, B, lam):
+    """sum_square(A X' - B) + lam * norm_1(X)  s.t.  X' - X = 0 for a matrix variable X (n x k):
+    the data map is the Kronecker product I_k (x) A acting on vec(X') (reference lasso.py with
+    k > 1, mnist.py:51-64; linear_map.proto KRONECKER_PRODUCT)."""
+    m, n = A.shape
+    k = B.shape[1]
+    Xp = ir.variable(n, k, "separate:var:X:sum_square")
+    X = ir.variable(n, k, "var:X")
+    f0 = ir.prox(ProxFunction.SUM_SQUARE,
+                 ir.add(ir.linear_map(ir.left_matrix_product(ir.dense_matrix(A), k), ir.reshape(Xp, n * k, 1)),
+                        ir.linear_map(ir.scalar(-1, m * k), ir.constant(B.reshape(-1, 1, order="F")))),
+                 alpha=1.0, arg_size=[(m * k, 1)])
+    f1 = ir.prox(ProxFunction.NORM_1, X, alpha=lam)
+    c = ir.zero(ir.add(ir.reshape(Xp, n * k, 1), ir.linear_map(ir.scalar(-1, n * k), ir.reshape(X, n * k, 1))))
+    return ir.Problem([f0, f1], [c])
+
+
+def mv_lasso(m, n, k, rho=0.01, sigma=0.05, seed=0):
+    """Multivariate lasso (reference problems/lasso.py with k > 1, benchmark.py:46: m=1500,
+    n=5000, k=10, rho=0.01): A with unit-l2 columns, X0 with support density rho,
+    B = A X0 + sigma randn, lam = 0.5 max|A^T B|."""
+    rng = np.random.RandomState(seed)
+    A = rng.randn(m, n)
+    A /= np.sqrt(np.sum(A ** 2, 0))
+    X0 = np.zeros((n, k))
+    nnz = int(round(rho * n * k))
+    idx = rng.choice(n * k, nnz, replace=False)
+    X0.reshape(-1)[idx] = rng.randn(nnz)
+    B = A.dot(X0) + sigma * rng.randn(m, k)
+    lam = 0.5 * np.abs(A.T.dot(B)).max()
+    return mv_lasso_ir(A, B, lam), dict(A=A, B=B, lam=lam)
+
+
+def mv_lasso_objective(A, B, lam, X):
+    return float(np.sum((A.dot(X) - B) ** 2) + lam * np.abs(X).sum())
+
+
+def mnist_random_features(X, n, rng):
+    """cos(Xp W + B) kitchen-sink features of reference problems/mnist.py:27-44: Xp = the data
+    projected on 50 eigenvectors of its scatter matrix when it has more rows than columns (the
+    reference takes the FIRST 50 columns of eigh's output - the smallest eigenvalues - and so does
+    this), sigma = the median distance of m^1.5 random pairs."""
+    X = np.asarray(X, dtype=np.float64)
+    if X.shape[0] >= X.shape[1]:
+        Xc = X - np.mean(X, axis=0)
+        _, D = np.linalg.eigh(Xc.T.dot(Xc))
+        Xp = X.dot(D[:, :50])
+    else:
+        Xp = X
+    mrows = Xp.shape[0]
+    kk = int(mrows ** 1.5)
+    I, J = rng.randint(0, mrows, kk), rng.randint(0, mrows, kk)
+    sigma = np.sort(np.linalg.norm(Xp[I] - Xp[J], axis=1))[kk // 2]
+    W = rng.randn(Xp.shape[1], n) / sigma / np.sqrt(2)
+    Bv = rng.uniform(0, 2 * np.pi, n)
+    return np.cos(Xp.dot(W) + Bv)
+
+
+def mnist_features_lasso(X, y, n=1000, lam=0.1, seed=0):
+    """The reference's "mnist" benchmark problem (problems/mnist.py:51-64, benchmark.py:45 on the
+    2000-sample mnist_small data): sum_squares(F Theta - Y) + 0.1 norm_1(Theta), F = n random
+    features, Y the one-hot labels, Theta n x 10."""
+    rng = np.random.RandomState(seed)
+    F = mnist_random_features(X, n, rng)
+    y = np.asarray(y).ravel().astype(int)
+    Y = np.zeros((len(y), int(y.max()) + 1))
+    Y[np.arange(len(y)), y] = 1.0
+    return mv_lasso_ir(F, Y, lam), dict(A=F, B=Y, lam=lam)
+
+
+def fused_lasso(m, ni, k, rho=0.05, sigma=0.05, seed=0):
+    """sum_squares(A x - b) + lam norm_1(x) + lam tv(x) (reference problems/fused_lasso.py,
+    benchmark.py:30: m=1000, ni=10, k=1000), in prox form: the least-squares term and the l1 term
+    work on copies tied to x by equality constraints, the total variation keeps x itself."""
+    rng = np.random.RandomState(seed)
+    n = ni * k
+    A = rng.randn(m, n)
+    A /= np.sqrt(np.sum(A ** 2, 0))
+    x0 = np.zeros(n)
+    for i in range(k):
+        if rng.rand() < rho:
+            x0[i * ni:(i + 1) * ni] = rng.rand()
+    b = A.dot(x0) + sigma * rng.randn(m)
+    lam = 0.1 * sigma * np.sqrt(m * np.log(n))
+    xs = ir.variable(n, 1, "separate:var:x:sum_square")
+    xl = ir.variable(n, 1, "separate:var:x:norm_1")
+    x = ir.variable(n, 1, "var:x")
+    f0 = ir.prox(ProxFunction.SUM_SQUARE,
+                 ir.add(ir.linear_map(ir.dense_matrix(A), xs), ir.linear_map(ir.scalar(-1, m), ir.constant(b))),
+                 alpha=1.0)
+    f1 = ir.prox(ProxFunction.NORM_1, xl, alpha=lam)
+    f2 = ir.prox(ProxFunction.TOTAL_VARIATION_1D, x, alpha=lam)
+    c0 = ir.zero(ir.add(xs, ir.linear_map(ir.scalar(-1, n), x)))
+    c1 = ir.zero(ir.add(xl, ir.linear_map(ir.scalar(-1, n), x)))
+    return ir.Problem([f0, f1, f2], [c0, c1]), dict(A=A, b=b, lam=lam)
+
+
+def fused_lasso_objective(A, b, lam, x):
+    return float(np.sum((A.dot(x) - b) ** 2) + lam * np.abs(x).sum() + lam * np.abs(np.diff(x)).sum())
+
+
 def logreg_l1(m, n, lam=None, seed=0):
     """sum_i logistic(-y_i a_i^T x) + lam ||x||_1 in graph form
     (reference python/epopt/problems/logreg_l1.py, compiled like docs/notebooks):

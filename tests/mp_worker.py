@@ -244,12 +244,16 @@ def main():
         prob = problems.lasso_ir(ir.dense_matrix(Ag), ir.constant(b), lam, ng)
         edist.mark_sharded(None, prob)
         params = wire.SolverParams(max_iterations=max_iter)
+        _solve.profile_enable(True)
+        _solve.profile_reset()
         st, x = _solve.solve(prob.SerializeToString(), [], params.SerializeToString(),
                              prob.expression_data())
+        tags = sorted(t.split(":")[0] for t in _solve.profile_dump())
+        _solve.profile_enable(False)
         S = wire.SolverStatus.FromString(st)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
                  x0=np.frombuffer(x["separate:var:x:sum_square"]), x1=np.frombuffer(x["var:x"]),
-                 lo=lo, hi=hi,
+                 lo=lo, hi=hi, tags=np.array(sorted(set(tags))),
                  status=np.array([S.num_iterations, S.residuals.r_norm, S.residuals.s_norm,
                                   S.residuals.epsilon_primal, S.residuals.epsilon_dual]),
                  state=S.state)

@@ -633,12 +633,15 @@ def test_lp_type_problems(solve_mod, dtype, name):
         np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
 
 
-@pytest.mark.parametrize("name", ["group_lasso", "logreg_l1", "covsel"])
+@pytest.mark.parametrize("name", ["group_lasso", "logreg_l1", "covsel", "mv_lasso", "fused_lasso"])
 def test_more_benchmark_problems(solve_mod, dtype, name):
     """Drivers over the batched NORM_2 (group lasso), SUM_LOGISTIC + ZERO graph form (l1 logistic
-    regression) and NEG_LOG_DET (sparse inverse covariance) operators: same stopping iteration
-    and iterates as the oracle."""
+    regression), NEG_LOG_DET (sparse inverse covariance), the Kronecker data map of a matrix
+    variable (multivariate lasso) and three terms on one variable (fused lasso: least squares +
+    l1 + total variation): same stopping iteration and iterates as the oracle."""
     prob, info = {"group_lasso": lambda: problems.group_lasso(30, 20, 3),
+                  "mv_lasso": lambda: problems.mv_lasso(30, 40, 3, rho=0.1),
+                  "fused_lasso": lambda: problems.fused_lasso(30, 4, 12, rho=0.3),
                   "logreg_l1": lambda: problems.logreg_l1(40, 15),
                   "covsel": lambda: problems.covsel(6)}[name]()
     params = wire.SolverParams(max_iterations=60)
@@ -989,18 +992,20 @@ def test_fused_sweep_sharded(solve_mod, tmp_path, apply_mode):
     np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=1e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("world,apply_mode,graph", [(2, "slab", "1"), (3, "slab", "0"), (3, "slab", "1"),
-                                                    (3, "replicated", "1")])
-def test_fused_sweep_sharded_peer_window(solve_mod, tmp_path, world, apply_mode, graph):
+@pytest.mark.parametrize("world,apply_mode,graph,dt", [(2, "slab", "1", "f32"), (3, "slab", "0", "f32"),
+                                                       (3, "slab", "1", "f32"), (3, "replicated", "1", "f32"),
+                                                       (3, "slab", "1", "f64"), (2, "replicated", "0", "f64")])
+def test_fused_sweep_sharded_peer_window(solve_mod, tmp_path, world, apply_mode, graph, dt):
     """The same solve with the per-sweep exchanges on the one-shot peer-write window
     (csrc/kernels_peer.hip): ranks are separate processes sharing this GPU, their windows are
     mapped into each other through HIP IPC, every rank writes its partial forward product / its
     slab of w straight into the peers' windows from inside the sweep's kernels; sweeps between
-    residual checks eager (graph 0) or replayed from a hipGraph (graph 1)."""
+    residual checks eager (graph 0) or replayed from a hipGraph (graph 1).  fp64: a value travels
+    as two granules (high word, low word), each its own flag; iterates to 1e-8 of the oracle's."""
     from tests import mp_util
     m, n = 40, 101
     x0, x1, status, parts = mp_util.run_ranks(world, "hip", str(tmp_path), m, n, seed=3,
-                                              env_extra={"EPS_TEST_DTYPE": "f32", "EPS_TEST_PEER": "1",
+                                              env_extra={"EPS_TEST_DTYPE": dt, "EPS_TEST_PEER": "1",
                                                          "EPSILON_HIP_GRAPH": graph,
                                                          "EPSILON_HIP_SHARDED_APPLY": apply_mode})
     prob, info = problems.lasso(m, n, seed=3)
@@ -1009,8 +1014,13 @@ def test_fused_sweep_sharded_peer_window(solve_mod, tmp_path, world, apply_mode,
     S = wire.SolverStatus.FromString(st)
     for s, p in zip(status, parts):
         assert int(p["state"]) == wire.SolverStatus.OPTIMAL and int(s[0]) == S.num_iterations
-    np.testing.assert_allclose(x0, np.frombuffer(x[problems.LASSO_COPY]), rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=1e-3, atol=1e-4)
+        tags = set(str(t) for t in p["tags"])
+        # the exchanges really rode on the window: no collective call inside the sweeps
+        assert "peer_reduce_exchange" in tags, sorted(tags)
+        assert ("peer_slab_apply_exchange" in tags) == (apply_mode == "slab"), sorted(tags)
+    rtol, atol = (1e-3, 1e-4) if dt == "f32" else (1e-8, 1e-10)
+    np.testing.assert_allclose(x0, np.frombuffer(x[problems.LASSO_COPY]), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(x1, np.frombuffer(x[problems.LASSO_VAR]), rtol=rtol, atol=atol)
 
 
 def test_peer_window_graph_replay_is_bit_identical(solve_mod, tmp_path):

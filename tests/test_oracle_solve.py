@@ -128,6 +128,40 @@ def test_group_lasso_problem():  # NORM_2 with an axis inside the driver
     assert obj <= opt * (1 + 1e-2) + 1e-4
 
 
+def test_mv_lasso_problem():  # Kronecker data map I_k (x) A on a matrix variable (lasso.py with k > 1)
+    prob, info = problems.mv_lasso(30, 40, 3, rho=0.1)
+    S, x = solve(prob, max_iterations=2000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    A, B, lam = info["A"], info["B"], info["lam"]
+    X = x["var:X"].reshape((40, 3), order="F")
+    obj = problems.mv_lasso_objective(A, B, lam, X)
+    L = 2 * np.linalg.norm(A, 2) ** 2
+    Z = np.zeros((40, 3))
+    for _ in range(20000):  # independent proximal-gradient solve
+        G = Z - 2 * A.T @ (A @ Z - B) / L
+        Z = np.sign(G) * np.maximum(np.abs(G) - lam / L, 0)
+    opt = problems.mv_lasso_objective(A, B, lam, Z)
+    assert obj <= opt * (1 + 1e-2) + 1e-4 and obj >= opt * (1 - 1e-6) - 1e-9
+
+
+def test_fused_lasso_problem():  # three terms on one variable: SUM_SQUARE + NORM_1 + TOTAL_VARIATION_1D
+    prob, info = problems.fused_lasso(30, 4, 12, rho=0.3)
+    S, x = solve(prob, max_iterations=3000)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    A, b, lam = info["A"], info["b"], info["lam"]
+    obj = problems.fused_lasso_objective(A, b, lam, x["var:x"])
+    # independent proximal-gradient solve: the prox of lam (||.||_1 + tv) is the soft threshold of
+    # the total-variation prox (Friedman et al. 2007), the latter from the C dynamic program
+    L = 2 * np.linalg.norm(A, 2) ** 2
+    z = np.zeros(A.shape[1])
+    for _ in range(5000):
+        g = z - 2 * A.T @ (A @ z - b) / L
+        t = c_oracle.tv1d(g, lam / L)
+        z = np.sign(t) * np.maximum(np.abs(t) - lam / L, 0)
+    opt = problems.fused_lasso_objective(A, b, lam, z)
+    assert obj <= opt * (1 + 1e-2) + 1e-4 and obj >= opt * (1 - 1e-6) - 1e-9
+
+
 def test_logreg_l1_problem():  # SUM_LOGISTIC + ZERO graph form
     prob, info = problems.logreg_l1(40, 15)
     S, x = solve(prob, max_iterations=500)
