@@ -165,7 +165,7 @@ int eps_comm_warmup(size_t count);
  * own kernels and sums what it received in rank order (csrc/kernels_peer.hip), and the sweeps
  * between two residual checks are replayed from one hipGraph.  The communicator above stays in
  * charge of the large setup messages and of the residual scalars.  `slot_floats` = largest
- * message (0: 16384); `rehearse_ranks` > 1 (single-rank communicator only) makes this process
+ * message in 32-bit words (an fp64 solve needs two per row of the m-vector; 0: 16384); `rehearse_ranks` > 1 (single-rank communicator only) makes this process
  * play ONE rank of that many for timing rehearsals on one GPU (results are not a solve's).
  * *enabled = 1 if every rank has the window and its self test passed, else 0 - then nothing
  * changes (RCCL per sweep) and eps_last_error() says why.  The reference has no counterpart
