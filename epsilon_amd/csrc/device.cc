@@ -343,6 +343,8 @@ template <class D> bool UploadThroughPinned(D* dev, const double* src, int64_t n
 }
 }  // namespace
 
+int HostThreadCount() { return HostThreads(); }
+
 DVec DVec::FromHost(const double* src, int64_t n, DType dt) {
   DVec v = Empty(n, dt);
   if (n == 0) return v;

@@ -128,6 +128,8 @@ struct ProfScope {
 // eps_set_option("dtype", ...)); maps without data of their own (scalars) take it from here.
 DType CurrentDType();
 void SetCurrentDType(DType dt);
+// host threads for large host-side copies / conversions (EPSILON_HIP_HOST_THREADS; at most 16)
+int HostThreadCount();
 
 // Typed device vector view.  Copying a DVec shares the buffer (like shared_ptr).
 struct DVec {

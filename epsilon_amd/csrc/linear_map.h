@@ -62,7 +62,7 @@ struct Blob {
   int kind = 0;     // 0 host bytes, 1 device f32, 2 device f64
   // Host blobs of a solver handle are COPIED at the boundary, as the reference copies every
   // blob into its DataMap (python/epopt/solvemodule.cc:58-72): `ptr` then points into `owned`.
-  std::shared_ptr<std::vector<char>> owned;
+  std::shared_ptr<char> owned;  // new char[len]: not value-initialised (the copy is the first touch)
 };
 
 // Data map {location -> blob} plus a cache of what was already uploaded, so one constant is
