@@ -48,6 +48,8 @@ def lib():
         L.eps_result_num_vars.restype = ctypes.c_size_t
         L.eps_result_num_vars.argtypes = [ctypes.c_void_p]
         L.eps_result_free.argtypes = [ctypes.c_void_p]
+        L.eps_result_copy_var.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        L.eps_result_copy_var.restype = ctypes.c_int
         L.eps_result_free.restype = None
         L.eps_solver_destroy.argtypes = [ctypes.c_void_p]
         L.eps_solver_destroy.restype = None
@@ -117,6 +119,15 @@ def _params(parameters, keep):
     return arr, len(items)
 
 
+_BIG_RESULT = 64 << 20
+_new_bytes = ctypes.pythonapi.PyBytes_FromStringAndSize
+_new_bytes.restype = ctypes.py_object
+_new_bytes.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t]
+_bytes_ptr = ctypes.pythonapi.PyBytes_AsString
+_bytes_ptr.restype = ctypes.c_void_p
+_bytes_ptr.argtypes = [ctypes.py_object]
+
+
 def _take_result(res):
     L = lib()
     try:
@@ -131,7 +142,17 @@ def _take_result(res):
             cnt = ctypes.c_size_t()
             L.eps_result_var(res, ctypes.c_size_t(i), ctypes.byref(cid), ctypes.byref(vals),
                              ctypes.byref(cnt))
-            out[cid.value.decode("utf-8")] = ctypes.string_at(vals, cnt.value * 8)
+            nbytes = cnt.value * 8
+            if nbytes >= _BIG_RESULT:
+                # an uninitialised bytes object filled by the library's host threads before anyone
+                # else sees it (the C-API contract of PyBytes_FromStringAndSize(NULL, n)); one
+                # thread's string_at of a 0.8 GB iterate costs 0.15-0.2 s
+                b = _new_bytes(None, nbytes)
+                if L.eps_result_copy_var(res, ctypes.c_size_t(i), _bytes_ptr(b), ctypes.c_size_t(nbytes)) != 0:
+                    raise error("eps_result_copy_var failed")
+                out[cid.value.decode("utf-8")] = b
+            else:
+                out[cid.value.decode("utf-8")] = ctypes.string_at(vals, nbytes)
         return status, out
     finally:
         L.eps_result_free(res)

@@ -22,7 +22,7 @@ using namespace eps;
 struct eps_result {
   std::string status;
   std::vector<std::string> ids;
-  std::vector<std::vector<double>> values;
+  std::vector<HostArray> values;  // not value-initialised, huge pages from 64 MB
 };
 
 struct eps_solver {
@@ -93,7 +93,7 @@ void FillResult(Solver* solver, eps_result* r) {
   BlockVector x = solver->GetSolution();
   for (const auto& var : GetVariables(solver->problem())) {  // solvemodule.cc:166-176
     r->ids.push_back(var.first);
-    r->values.push_back(x(var.first).ToHost());
+    r->values.push_back(x(var.first).ToHostArray());
   }
 }
 
@@ -191,7 +191,7 @@ int eps_eval_prox(const void* f_expr, size_t f_expr_len, double lambda, const ep
     std::unique_ptr<eps_result> r(new eps_result);
     for (const auto& kv : x.data()) {  // GetVariableMap, solvemodule.cc:45-56
       r->ids.push_back(kv.first);
-      r->values.push_back(kv.second.ToHost());
+      r->values.push_back(kv.second.ToHostArray());
     }
     *out = r.release();
   });
@@ -212,6 +212,12 @@ int eps_result_var(const eps_result* r, size_t i, const char** id, const double*
   if (id) *id = r->ids[i].c_str();
   if (values) *values = r->values[i].data();
   if (count) *count = r->values[i].size();
+  return 0;
+}
+
+int eps_result_copy_var(const eps_result* r, size_t i, void* dst, size_t bytes) {
+  if (!r || i >= r->ids.size() || dst == nullptr || bytes != r->values[i].size() * sizeof(double)) return 1;
+  ParallelHostCopy(dst, r->values[i].data(), bytes);
   return 0;
 }
 

@@ -130,8 +130,24 @@ DType CurrentDType();
 void SetCurrentDType(DType dt);
 // host threads for large host-side copies / conversions (EPSILON_HIP_HOST_THREADS; at most 16)
 int HostThreadCount();
+// `bytes` of host memory that is NOT value-initialised; from 64 MB on 2 MB-aligned with a
+// transparent-huge-page hint (the page faults, not the bytes, bound the first write of a fresh
+// buffer of several hundred MB).
+std::shared_ptr<char> AllocHostBuffer(size_t bytes);
+// dst[lo, hi) <- src, split over the host threads in stripes (large copies only)
+void ParallelHostCopy(void* dst, const void* src, size_t bytes);
 
 // Typed device vector view.  Copying a DVec shares the buffer (like shared_ptr).
+
+// float64 values on the host in a buffer from AllocHostBuffer (results at the boundary)
+struct HostArray {
+  std::shared_ptr<char> mem;
+  size_t n = 0;
+  double* data() { return reinterpret_cast<double*>(mem.get()); }
+  const double* data() const { return reinterpret_cast<const double*>(mem.get()); }
+  size_t size() const { return n; }
+};
+
 struct DVec {
   std::shared_ptr<Buffer> buf;
   size_t offset = 0;  // bytes
@@ -154,6 +170,7 @@ struct DVec {
   DVec Clone() const;
   std::vector<double> ToHost() const;  // synchronises
   void ToHost(double* dst) const;
+  HostArray ToHostArray() const;  // the same into a buffer that is not value-initialised first
 };
 
 }  // namespace eps

@@ -1,10 +1,5 @@
 #include "linear_map.h"
 
-#include <sys/mman.h>
-
-#include <cstring>
-#include <thread>
-
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -66,35 +61,11 @@ void DataMap::InsertOwned(const std::string& key, Blob b) {
     EPS_CHECK_MSG(b.ptr != nullptr, "host blob '" << key << "' has a null pointer");
     const char* src = static_cast<const char*>(b.ptr);
     // A large blob (the 376 MB data matrix of the MNIST-shape problem) is copied by the host
-    // threads in stripes: one thread's memcpy into freshly mapped pages runs at ~6 GB/s (64 ms),
-    // the page faults and the copy both scale with the threads.
-    const size_t len = b.len;
-    if (len >= (size_t(64) << 20)) {
-      // 2 MB alignment + a transparent-huge-page hint: 512 times fewer page faults where the
-      // kernel honours it (the faults, not the bytes, bound the copy of a fresh 376 MB buffer)
-      void* mem = nullptr;
-      EPS_CHECK_MSG(posix_memalign(&mem, size_t(2) << 20, (len + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1)) == 0,
-                    "host blob '" << key << "': out of memory");
-      (void)madvise(mem, len, MADV_HUGEPAGE);
-      b.owned = std::shared_ptr<char>(static_cast<char*>(mem), [](char* q) { std::free(q); });
-    } else {
-      b.owned = std::shared_ptr<char>(new char[len], std::default_delete<char[]>());
-    }
+    // threads in stripes into huge pages: one thread's memcpy into freshly mapped 4 KB pages runs
+    // at ~6 GB/s (64 ms), the page faults and the copy both scale with the threads (4 ms).
+    b.owned = AllocHostBuffer(b.len);
     char* dst = b.owned.get();
-    const int T = static_cast<int>(std::min<size_t>(static_cast<size_t>(HostThreadCount()), (len + (size_t(8) << 20) - 1) >> 23));
-    if (T <= 1) {
-      std::memcpy(dst, src, len);
-    } else {
-      std::vector<std::thread> th;
-      th.reserve(static_cast<size_t>(T));
-      for (int t = 0; t < T; ++t)
-        th.emplace_back([=] {
-          // stripes on 4 KB boundaries
-          const size_t lo = (len / T * t) & ~size_t(4095), hi = t + 1 == T ? len : (len / T * (t + 1)) & ~size_t(4095);
-          std::memcpy(dst + lo, src + lo, hi - lo);
-        });
-      for (auto& x : th) x.join();
-    }
+    ParallelHostCopy(dst, src, b.len);
     b.ptr = dst;
   }
   Insert(key, b);

@@ -107,6 +107,11 @@ int eps_result_status(const eps_result* r, const void** bytes, size_t* len);
 size_t eps_result_num_vars(const eps_result* r);
 int eps_result_var(const eps_result* r, size_t i, const char** id, const double** values,
                    size_t* count);
+/* Copies variable i's values (count * 8 bytes) into the caller's buffer with the library's host
+ * threads - the binding's replacement for one thread's memcpy of a 0.8 GB iterate into a fresh
+ * Python bytes object (solvemodule.cc:166-176 builds each output string the same way, one copy).
+ * 1 if i is out of range or `bytes` is not the variable's size. */
+int eps_result_copy_var(const eps_result* r, size_t i, void* dst, size_t bytes);
 void eps_result_free(eps_result* r);
 
 /* ---- solver handles: warm start, staged runs, timing --------------------------------------- */
