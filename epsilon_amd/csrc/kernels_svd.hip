@@ -298,7 +298,7 @@ __device__ __forceinline__ double Sum8D(double v) {
 
 __global__ __launch_bounds__(512) void SmallJacobiSvdFastKernel(float* Wg, int m, int n, float* Vg, int npad,
                                                                 int mp, int np, double tol, int max_sweeps,
-                                                                int warm, int* sweeps_out) {
+                                                                int warm, int* sweeps_out, int keep_v) {
   extern __shared__ __attribute__((aligned(16))) unsigned char small_svd_lds[];
   const int ldw = mp + 4, ldv = np + 4;
   float* W = reinterpret_cast<float*>(small_svd_lds);  // n columns of ldw floats
@@ -310,12 +310,15 @@ __global__ __launch_bounds__(512) void SmallJacobiSvdFastKernel(float* Wg, int m
     const int c = i / ldw, r = i - c * ldw;
     W[i] = r < m ? Wg[r + c * m] : 0.0f;
   }
-  for (int i = tid; i < n * ldv; i += nthreads) {
-    const int c = i / ldv, r = i - c * ldv;
-    V[i] = r < n ? (warm ? Vg[r + c * n] : (r == c ? 1.0f : 0.0f)) : 0.0f;
-  }
+  // keep_v == 0: the rotations go to W alone (the caller needs one orthonormal side only and
+  // re-forms the other from the matrix: JacobiSvdNoV) - no V in LDS, half the LDS traffic of a step
+  if (keep_v)
+    for (int i = tid; i < n * ldv; i += nthreads) {
+      const int c = i / ldv, r = i - c * ldv;
+      V[i] = r < n ? (warm ? Vg[r + c * n] : (r == c ? 1.0f : 0.0f)) : 0.0f;
+    }
   const int pair = tid >> 3, sub = tid & 7;
-  const int rw4 = mp / 32, rv4 = np / 32;  // float4 per lane and column (<= 4)
+  const int rw4 = mp / 32, rv4 = keep_v ? np / 32 : 0;  // float4 per lane and column (<= 4)
   const int ring = npad - 1;
   int sweeps = 0;
   for (; sweeps < max_sweeps; ++sweeps) {
@@ -433,24 +436,30 @@ __global__ __launch_bounds__(512) void SmallJacobiSvdFastKernel(float* Wg, int m
     const int c = i / m, r = i - c * m;
     Wg[i] = W[c * ldw + r];
   }
-  for (int i = tid; i < n * n; i += nthreads) {
-    const int c = i / n, r = i - c * n;
-    Vg[i] = V[c * ldv + r];
-  }
+  if (keep_v)
+    for (int i = tid; i < n * n; i += nthreads) {
+      const int c = i / n, r = i - c * n;
+      Vg[i] = V[c * ldv + r];
+    }
   if (tid == 0) *sweeps_out = sweeps;
 }
 
-// false: shape outside the fast kernel's range (the general kernel takes it)
-bool SmallJacobiSvdFast(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, double tol,
-                        bool warm, int* sweeps) {
+bool SmallFastEnabled() {
   static const bool off = [] {
     const char* e = std::getenv("EPSILON_HIP_SVD_SMALL_FAST");
     return e && e[0] == '0';
   }();
-  if (off || m > 128 || n > 128 || n < 2) return false;
+  return !off;
+}
+
+// false: shape outside the fast kernel's range (the general kernel takes it).  keep_v == false: V is
+// not touched (may be an empty DVec).
+bool SmallJacobiSvdFast(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_sweeps, double tol,
+                        bool warm, int* sweeps, bool keep_v = true) {
+  if (!SmallFastEnabled() || m > 128 || n > 128 || n < 2) return false;
   const int64_t npad = n + (n & 1);
   const int mp = static_cast<int>((m + 31) / 32 * 32), np = static_cast<int>((n + 31) / 32 * 32);
-  const size_t bytes = static_cast<size_t>(n) * (mp + 4 + np + 4) * sizeof(float);
+  const size_t bytes = static_cast<size_t>(n) * (mp + 4 + (keep_v ? np + 4 : 0)) * sizeof(float);
   if (bytes > kSmallLdsBytes) return false;
   static const bool big_lds_ok = [] {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&SmallJacobiSvdFastKernel),
@@ -464,11 +473,14 @@ bool SmallJacobiSvdFast(const DVec& W, int64_t m, int64_t n, const DVec& V, int 
   int threads = static_cast<int>(((npad / 2) * 8 + 63) / 64 * 64);
   threads = std::max(64, std::min(threads, 512));
   hipLaunchKernelGGL(SmallJacobiSvdFastKernel, dim3(1), dim3(threads), bytes, s, W.as<float>(),
-                     static_cast<int>(m), static_cast<int>(n), V.as<float>(), static_cast<int>(npad), mp, np, tol,
-                     max_sweeps, warm ? 1 : 0, static_cast<int*>(out->p));
+                     static_cast<int>(m), static_cast<int>(n), keep_v ? V.as<float>() : static_cast<float*>(nullptr),
+                     static_cast<int>(npad), mp, np, tol, max_sweeps, warm ? 1 : 0, static_cast<int*>(out->p),
+                     keep_v ? 1 : 0);
   EPS_HIP(hipGetLastError());
-  EPS_HIP(hipMemcpyAsync(sweeps, out->p, sizeof(int), hipMemcpyDeviceToHost, s));
-  EPS_HIP(hipStreamSynchronize(s));
+  if (sweeps != nullptr) {  // (nullptr: nobody wants the count - no host synchronisation)
+    EPS_HIP(hipMemcpyAsync(sweeps, out->p, sizeof(int), hipMemcpyDeviceToHost, s));
+    EPS_HIP(hipStreamSynchronize(s));
+  }
   return true;
 }
 
@@ -1318,7 +1330,11 @@ int BlockJacobiSvd(const DVec& W, int64_t m, int64_t n, const DVec& V, int max_s
 // block form on the matrix cores, where JacobiSvd would route it; not with the scalar / on-chip
 // kernels, for which V costs next to nothing.)
 bool JacobiSvdCanSkipV(int64_t m, int64_t n, DType dt) {
-  if (dt != F32 || m == 0 || n < 512) return false;
+  if (dt != F32 || m == 0) return false;
+  // the one-launch on-chip kernel (robust PCA at the reference's published size, n = 100)
+  const char* form = std::getenv("EPSILON_HIP_SVD");  // "scalar" | "block": a forced form keeps its old routes
+  const bool on_chip = m <= 128 && n <= 128 && n >= 2 && SmallFastEnabled() && !(form && form[0] != 0);
+  if (!on_chip && n < 512) return false;
   if (const char* env = std::getenv("EPSILON_HIP_SVD")) {
     if (env[0] == 's') return false;
   }
@@ -1336,6 +1352,16 @@ bool JacobiSvdCanSkipV(int64_t m, int64_t n, DType dt) {
 // singular values.  Requires JacobiSvdCanSkipV(m, n, W.dt).
 int JacobiSvdNoV(const DVec& W, int64_t m, int64_t n, int max_sweeps) {
   EPS_CHECK(W.n >= m * n && JacobiSvdCanSkipV(m, n, W.dt));
+  if (m <= 128 && n <= 128) {
+    ProfScope prof("jacobi_svd_no_v_on_chip", m, n);
+    static const bool verbose = std::getenv("EPSILON_HIP_SVD_VERBOSE") != nullptr;
+    int done = -1;  // unknown unless asked for: fetching the count would stall the host once per prox
+    EPS_CHECK(SmallJacobiSvdFast(W, m, n, DVec(), max_sweeps, 2e-7, false, verbose ? &done : nullptr, false));
+    if (verbose)
+      std::fprintf(stderr, "[svd] on-chip (no V) %lld x %lld: %d sweeps\n", static_cast<long long>(m),
+                   static_cast<long long>(n), done);
+    return done;
+  }
   ProfScope prof("block_jacobi_svd_no_v", m, n);
   // de Rijk's ordering - columns by decreasing norm before the sweeps (the caller does not care in
   // which order the orthogonal columns come back) - measured at n = 1e4 on the reference's
