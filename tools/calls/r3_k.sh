@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-bash tools_gpu_r3_tv.sh r3k 2>&1 | grep -E "n=|per level|passed|failed"
+bash tools/calls/r3_tv.sh r3k 2>&1 | grep -E "n=|per level|passed|failed"
 for srt in 1 0; do
   echo "--- nuclear prox n=1e4, EPSILON_HIP_SVD_SORT=$srt"
   EPSILON_HIP_SVD_SORT=$srt EPSILON_HIP_SVD_VERBOSE=1 timeout -k 10 300 python3 tools_bench_nuclear_prox.py 10000 > $O/r3k_nuclear_sort$srt.jsonl 2> $O/r3k_nuclear_sort$srt.err
