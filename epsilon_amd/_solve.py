@@ -305,6 +305,13 @@ def block_solve_stats(reset=False):
     return c.value, r.value
 
 
+def graph_stats(reset=False):
+    """(sweeps of the generic operator path replayed from a hipGraph, captures) since the last reset."""
+    a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _check(lib().eps_graph_stats(ctypes.byref(a), ctypes.byref(b), ctypes.c_int(1 if reset else 0)))
+    return a.value, b.value
+
+
 def profile_enable(on=True):
     _check(lib().eps_profile_enable(ctypes.c_int(1 if on else 0)))
 

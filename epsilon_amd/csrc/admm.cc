@@ -11,6 +11,12 @@
 
 namespace eps {
 
+GraphStats& GraphStats::Get() {
+  static GraphStats g;
+  return g;
+}
+
+
 namespace {
 
 double Now() {
@@ -184,6 +190,197 @@ void Solver::Solve() {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The generic operator path's sweeps between two residual checks as ONE hipGraph (small problems
+// are bound by launch latency: 30-60 launches of a few microseconds per sweep).  BlockVector
+// blocks are replaced, never mutated, so a sweep ends in other buffers than it started from; the
+// capture therefore runs on CANONICAL copies of the state (shared with this object, hence
+// copy-on-write keeps the sweep from writing into them) and ends with device-to-device copies of
+// the final blocks back into them: every replay starts and ends at the same addresses.  All
+// buffers the captured launches touch are fenced off by a Runtime hold for the graph's life.
+// Only for problems whose operators are all ProxOperator::CaptureSafe and whose state is small.
+// ---------------------------------------------------------------------------------------------------
+class SweepGraph {
+ public:
+  ~SweepGraph() { Reset(); }
+
+  void Reset() {
+    if (exec_) (void)hipGraphExecDestroy(exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    exec_ = nullptr;
+    graph_ = nullptr;
+    len_ = 0;
+    if (!held_.empty()) Runtime::Get().ReturnHeld(&held_);  // (stream order keeps the reuse safe)
+    canon_.clear();
+  }
+  void ClearFailure() { failed_ = false; }
+
+  // MEASURED, AND OFF BY DEFAULT (round 3, ROCm 7.2, MI355X): replaying the generic sweeps from a
+  // graph is bit-identical to the eager launches (tests) and buys nothing - 1000 sweeps of the
+  // reference's lasso_sparse / mnist / mv_lasso problems take 0.102 / 0.312 / 0.104 s replayed
+  // against 0.093 / 0.320 / 0.104 s eager: the host already runs far ahead of the stream, and the
+  // gap between two dependent kernels is the same inside a graph - while capturing and
+  // instantiating a batch costs 4-5 ms, more than most solves of these problems take in all.
+  // EPSILON_HIP_GRAPH_GENERIC (option "graph_generic") = 1: once a run has lasted kEagerFirst
+  // sweeps; = 2: after the first sweep (tests); 0 / unset: never.  Read per call.
+  static constexpr int kEagerFirst = 50;
+  static int Mode() {
+    const char* e = std::getenv("EPSILON_HIP_GRAPH_GENERIC");
+    return e ? std::atoi(e) : 0;
+  }
+  static int EagerSweepsFirst() { return Mode() >= 2 ? 1 : kEagerFirst; }
+
+  bool Wanted(int count, const std::vector<BlockVector*>& state) const {
+    const int gmode = Mode();
+    Runtime& rt = Runtime::Get();
+    if (gmode == 0 || count < 2 || failed_) return false;
+    if (rt.profiling() || rt.capturing() || rt.holding() || ShardSpec::Get().active()) return false;
+    // launch-bound problems only: the copies back cost a pass over the state per batch
+    int64_t bytes = 0;
+    for (const BlockVector* v : state)
+      for (const auto& kv : v->data()) bytes += static_cast<int64_t>(kv.second.bytes());
+    return bytes <= (int64_t(64) << 20);
+  }
+
+  // Replays `count` sweeps (capturing first when there is no graph of that length, or when
+  // somebody re-bound the state since).  false: nothing was enqueued - the caller launches eagerly.
+  // The first `n_prev` handles are "previous iterate" copies that every sweep overwrites before it
+  // reads them (y_prev = y): their layout before the capture does not matter.
+  template <class SweepFn>
+  bool Run(int count, const std::vector<BlockVector*>& state, size_t n_prev, SweepFn sweep) {
+    if (exec_ == nullptr || len_ != count || !IsCanonical(state)) Capture(count, state, n_prev, sweep);
+    if (exec_ == nullptr) return false;
+    EPS_HIP(hipGraphLaunch(exec_, Runtime::Get().stream()));
+    GraphStats::Get().replayed_sweeps += count;
+    return true;
+  }
+
+ private:
+  static bool SameBuffers(const BlockVector& a, const BlockVector& b) {
+    if (a.data().size() != b.data().size()) return false;
+    auto ia = a.data().begin();
+    auto ib = b.data().begin();
+    for (; ia != a.data().end(); ++ia, ++ib)
+      if (ia->first != ib->first || ia->second.data() != ib->second.data() || ia->second.n != ib->second.n)
+        return false;
+    return true;
+  }
+  static BlockVector CloneBlocks(const BlockVector& v) {
+    BlockVector c;
+    for (const auto& kv : v.data()) c.Set(kv.first, kv.second.Clone());
+    return c;
+  }
+  // dst (canonical) <- src, block by block, on the stream; false: the layouts differ
+  static bool CopyBlocksBack(const BlockVector& dst, const BlockVector& src) {
+    if (dst.data().size() != src.data().size()) return false;
+    hipStream_t s = Runtime::Get().stream();
+    auto id = dst.data().begin();
+    auto is = src.data().begin();
+    for (; id != dst.data().end(); ++id, ++is) {
+      if (id->first != is->first || id->second.n != is->second.n || id->second.dt != is->second.dt) return false;
+      if (id->second.data() == is->second.data() || id->second.n == 0) continue;
+      EPS_HIP(hipMemcpyAsync(const_cast<void*>(static_cast<const void*>(id->second.data())), is->second.data(),
+                             id->second.bytes(), hipMemcpyDeviceToDevice, s));
+    }
+    return true;
+  }
+  bool IsCanonical(const std::vector<BlockVector*>& state) const {
+    if (state.size() != canon_.size()) return false;
+    for (size_t i = 0; i < state.size(); ++i)
+      if (!SameBuffers(*state[i], canon_[i])) return false;
+    return true;
+  }
+
+  // `state`: every BlockVector a sweep reads from the one before it, "previous iterate" handles
+  // FIRST (a block the last sweep left alone may still be the canonical buffer of its successor,
+  // which the copies back overwrite afterwards).
+  template <class SweepFn>
+  void Capture(int count, const std::vector<BlockVector*>& state, size_t n_prev, SweepFn sweep) {
+    Runtime& rt = Runtime::Get();
+    hipStream_t s = rt.stream();
+    Reset();
+    std::vector<BlockVector> saved;  // the handles as they are, should the capture be abandoned
+    for (BlockVector* v : state) {
+      saved.push_back(*v);
+      canon_.push_back(CloneBlocks(*v));
+    }
+    rt.BeginHold();
+    for (size_t i = 0; i < state.size(); ++i) *state[i] = canon_[i];
+    bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
+    hipGraph_t graph = nullptr;
+    std::string why;
+    if (ok) {
+      rt.set_capturing(true);
+      try {
+        for (int i = 0; i < count; ++i) sweep();
+        for (size_t i = 0; i < state.size() && ok; ++i) {
+          ok = CopyBlocksBack(canon_[i], *state[i]);
+          if (!ok && i < n_prev) {  // written before read: its canonical buffers take today's layout
+            BlockVector fresh;
+            for (const auto& kv : state[i]->data()) fresh.Set(kv.first, DVec::Empty(kv.second.n, kv.second.dt));
+            canon_[i] = fresh;
+            ok = CopyBlocksBack(canon_[i], *state[i]);
+          }
+          if (!ok) {
+            why = "the block layout of state handle " + std::to_string(i) + " changed during the sweeps: had";
+            for (const auto& kv : canon_[i].data()) why += " " + kv.first + ":" + std::to_string(kv.second.n);
+            why += "; has";
+            for (const auto& kv : state[i]->data()) why += " " + kv.first + ":" + std::to_string(kv.second.n);
+          }
+        }
+      } catch (const std::exception& e) {
+        ok = false;
+        why = e.what();
+      } catch (...) {
+        ok = false;
+        why = "exception";
+      }
+      rt.set_capturing(false);
+      const hipError_t ee = hipStreamEndCapture(s, &graph);
+      if (ee != hipSuccess || graph == nullptr) {
+        if (ok) why = std::string("hipStreamEndCapture: ") + hipGetErrorString(ee);
+        ok = false;
+      }
+    } else {
+      why = "hipStreamBeginCapture failed";
+    }
+    if (ok) {
+      const hipError_t ei = hipGraphInstantiate(&exec_, graph, nullptr, nullptr, 0);
+      if (ei != hipSuccess) {
+        ok = false;
+        why = std::string("hipGraphInstantiate: ") + hipGetErrorString(ei);
+      }
+    }
+    if (!ok) {
+      static const bool trace = std::getenv("EPSILON_HIP_GRAPH_TRACE") != nullptr;
+      if (trace) std::fprintf(stderr, "[graph] capture of %d generic sweeps abandoned: %s\n", count, why.c_str());
+      (void)hipGetLastError();
+      if (graph) (void)hipGraphDestroy(graph);
+      exec_ = nullptr;
+      for (size_t i = 0; i < state.size(); ++i) *state[i] = saved[i];  // nothing ran: the state is where it was
+      std::vector<std::pair<size_t, void*>> held = rt.EndHold();
+      rt.ReturnHeld(&held);
+      Reset();
+      failed_ = true;
+      return;
+    }
+    graph_ = graph;
+    len_ = count;
+    ++GraphStats::Get().captures;
+    for (size_t i = 0; i < state.size(); ++i) *state[i] = canon_[i];  // the last sweep's handles go to the held pool
+    saved.clear();
+    held_ = rt.EndHold();
+  }
+
+  hipGraph_t graph_ = nullptr;
+  hipGraphExec_t exec_ = nullptr;
+  int len_ = 0;
+  bool failed_ = false;  // a capture did not work out: the solver stays on eager launches
+  std::vector<std::pair<size_t, void*>> held_;
+  std::vector<BlockVector> canon_;
+};
+
+
+// ---------------------------------------------------------------------------------------------------
 // ProxADMMSolver (reference algorithms/prox_admm.cc)
 // ---------------------------------------------------------------------------------------------------
 
@@ -219,6 +416,10 @@ class ProxADMMSolver final : public Solver {
     initialized_ = true;
     TryEnableFused();
     mark("fused state");
+    capture_safe_ = true;
+    for (const auto& op : prox_) capture_safe_ = capture_safe_ && op->CaptureSafe();
+    eager_sweeps_ = 0;
+    gg_.ClearFailure();
     if (params_.verbose && log_) {
       char buf[128];
       std::snprintf(buf, sizeof(buf), "constraints, m = %lld, variables, n = %lld",
@@ -492,6 +693,25 @@ class ProxADMMSolver final : public Solver {
     graph_exec_ = nullptr;
     graph_ = nullptr;
     graph_len_ = 0;
+    ResetGenericGraph();
+  }
+
+  void ResetGenericGraph() { gg_.Reset(); }
+
+  std::vector<BlockVector*> StateHandles() {  // (the "previous" handles first: see SweepGraph::Capture)
+    std::vector<BlockVector*> h;
+    for (int i = 0; i < N_; ++i) h.push_back(&y_prev_[i]);
+    h.push_back(&u_);
+    for (int i = 0; i < N_; ++i) h.push_back(&x_[i]);
+    for (int i = 0; i < N_; ++i) h.push_back(&y_[i]);
+    return h;
+  }
+
+  bool GenericGraphWanted(int count) {
+    if (fused_ || !capture_safe_ || eager_sweeps_ < SweepGraph::EagerSweepsFirst() ||
+        static_cast<int>(y_prev_.size()) != N_)
+      return false;
+    return gg_.Wanted(count, StateHandles());
   }
 
   // The sweeps between two residual checks replayed from one hipGraph: a sharded sweep is 3
@@ -504,6 +724,7 @@ class ProxADMMSolver final : public Solver {
       return e ? std::atoi(e) : -1;
     }();
     Runtime& rt = Runtime::Get();
+    if (GenericGraphWanted(count) && gg_.Run(count, StateHandles(), static_cast<size_t>(N_), [this] { Sweep(); })) return;
     const ShardSpec& sh = ShardSpec::Get();
     const bool rccl_in_sweep = fused_ && !fs_.use_peer && sh.active() && sh.IsSharded(fs_.ls.var_key);
     const bool fixed_buffers = (fs_.use_peer && fs_.peer_slab) || fs_.symv_work.n > 0;
@@ -511,6 +732,7 @@ class ProxADMMSolver final : public Solver {
                       (mode == 1 || (mode != 0 && fs_.use_peer));
     if (!want || count < 2 || rt.profiling()) {
       for (int i = 0; i < count; ++i) Sweep();
+      if (!fused_) eager_sweeps_ += count;
       return;
     }
     if (graph_exec_ == nullptr || graph_len_ != count) {
@@ -721,6 +943,9 @@ class ProxADMMSolver final : public Solver {
   hipGraph_t graph_ = nullptr;
   hipGraphExec_t graph_exec_ = nullptr;
   int graph_len_ = 0;
+  SweepGraph gg_;  // the generic operator path's sweeps between two checks as one hipGraph
+  bool capture_safe_ = false;  // every prox operator of the problem is (ProxOperator::CaptureSafe)
+  int eager_sweeps_ = 0;       // operators build lazily on their first Apply: one eager sweep first
   BlockVector u_;
   std::vector<BlockVector> x_, y_, y_prev_;
 };
@@ -794,11 +1019,26 @@ class ProxADMMTwoBlockSolver final : public Solver {
     status_ = pb::SolverStatus();
     initialized_ = true;
     TryEnableFused();
+    gg_.Reset();
+    gg_.ClearFailure();
+    capture_safe_ = constr_prox_ != nullptr && constr_prox_->CaptureSafe();
+    for (const auto& op : prox_) capture_safe_ = capture_safe_ && op->CaptureSafe();
+    eager_sweeps_ = 0;
     Runtime::Get().Sync();
     init_seconds_ = Now() - t0;
   }
 
   BlockVector GetSolution() override { return x_; }
+
+  // the sweeps between two residual checks: one hipGraph where the operators allow it (SweepGraph)
+  void SweepBatch(int count) override {
+    if (!fused_ && capture_safe_ && eager_sweeps_ >= SweepGraph::EagerSweepsFirst()) {
+      const std::vector<BlockVector*> state = {&z_prev_, &x_, &z_, &u_};
+      if (gg_.Wanted(count, state) && gg_.Run(count, state, 1, [this] { Sweep(); })) return;
+    }
+    for (int i = 0; i < count; ++i) Sweep();
+    if (!fused_) eager_sweeps_ += count;
+  }
 
  protected:
   // ---- fused sweep for "least squares + separable threshold" problems, two-block form -----------
@@ -964,6 +1204,9 @@ class ProxADMMTwoBlockSolver final : public Solver {
   bool fused_ = false;
   FusedState fs_;
   BlockVector x_, z_, u_, z_prev_;
+  SweepGraph gg_;
+  bool capture_safe_ = false;
+  int eager_sweeps_ = 0;
 };
 
 std::unique_ptr<Solver> CreateSolver(pb::Problem problem, std::shared_ptr<DataMap> data,

@@ -87,4 +87,10 @@ std::unique_ptr<Solver> CreateSolver(pb::Problem problem, std::shared_ptr<DataMa
 BlockVector EvalProx(const pb::Expression& f_expr, double lambda, DataMap* data,
                      const BlockVector& v);
 
+// generic-path graph replay counters (eps_graph_stats)
+struct GraphStats {
+  long long replayed_sweeps = 0, captures = 0;
+  static GraphStats& Get();
+};
+
 }  // namespace eps

@@ -131,6 +131,8 @@ int eps_set_option(const char* key, const char* value) {
       Runtime::Get().set_prof_filter(value);
     } else if (std::strcmp(key, "fused") == 0) {
       setenv("EPSILON_HIP_FUSED", value, 1);
+    } else if (std::strcmp(key, "graph_generic") == 0) {
+      setenv("EPSILON_HIP_GRAPH_GENERIC", value, 1);
     } else if (std::strcmp(key, "refine") == 0) {
       if (std::strcmp(value, "auto") == 0) unsetenv("EPSILON_HIP_REFINE");
       else setenv("EPSILON_HIP_REFINE", value, 1);
@@ -400,6 +402,15 @@ int eps_block_solve_stats(double* max_condition, int* max_refine_steps, int rese
     if (max_condition) *max_condition = st.max_condition;
     if (max_refine_steps) *max_refine_steps = st.max_refine_steps;
     if (reset) st.Reset();
+  });
+}
+
+int eps_graph_stats(long long* replayed_sweeps, long long* captures, int reset) {
+  return Guard([&] {
+    GraphStats& g = GraphStats::Get();
+    if (replayed_sweeps) *replayed_sweeps = g.replayed_sweeps;
+    if (captures) *captures = g.captures;
+    if (reset) g = GraphStats();
   });
 }
 

@@ -56,7 +56,12 @@ std::shared_ptr<Buffer> Runtime::Alloc(size_t bytes) {
   auto b = std::make_shared<Buffer>();
   b->bytes = bytes;
   auto it = pool_.find(bytes);
-  if (it != pool_.end()) {
+  auto hit = holding_ ? hold_pool_.find(bytes) : hold_pool_.end();
+  if (hit != hold_pool_.end()) {
+    b->p = hit->second;
+    hold_pool_.erase(hit);
+    pooled_ -= bytes;
+  } else if (it != pool_.end()) {
     b->p = it->second;
     pool_.erase(it);
     pooled_ -= bytes;
@@ -76,16 +81,39 @@ std::shared_ptr<Buffer> Runtime::Alloc(size_t bytes) {
 void Runtime::Release(void* p, size_t bytes) {
   // Single-stream ordering makes immediate reuse safe: any kernel that touched `p` was
   // enqueued before whatever the next owner enqueues.
-  pool_.emplace(bytes, p);
+  (holding_ ? hold_pool_ : pool_).emplace(bytes, p);
   in_use_ -= bytes;
   pooled_ += bytes;
 }
 
+void Runtime::BeginHold() {
+  EPS_CHECK_MSG(!holding_, "nested buffer holds");
+  holding_ = true;
+}
+
+std::vector<std::pair<size_t, void*>> Runtime::EndHold() {
+  holding_ = false;
+  std::vector<std::pair<size_t, void*>> held(hold_pool_.begin(), hold_pool_.end());
+  hold_pool_.clear();
+  for (const auto& kv : held) pooled_ -= kv.first;  // neither pooled nor in use: the graph's
+  return held;
+}
+
+void Runtime::ReturnHeld(std::vector<std::pair<size_t, void*>>* held) {
+  for (const auto& kv : *held) {
+    pool_.emplace(kv.first, kv.second);
+    pooled_ += kv.first;
+  }
+  held->clear();
+}
+
 void Runtime::TrimPool() {
   EPS_HIP(hipStreamSynchronize(stream_));
-  for (auto& kv : pool_) (void)hipFree(kv.second);
+  for (auto& kv : pool_) {
+    (void)hipFree(kv.second);
+    pooled_ -= kv.first;
+  }
   pool_.clear();
-  pooled_ = 0;
 }
 
 void* Runtime::Scratch(size_t bytes) {

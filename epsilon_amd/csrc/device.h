@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -42,6 +43,14 @@ class Runtime {
   std::shared_ptr<Buffer> Alloc(size_t bytes);
   void Release(void* p, size_t bytes);
   void TrimPool();
+  // A "hold" fences the buffers a captured hipGraph touches off from everybody else: while it is
+  // active every released buffer goes to a private pool (which allocations inside the hold may
+  // re-use); EndHold() hands that pool to the caller, who keeps it for as long as the graph may
+  // be replayed and gives it back with ReturnHeld().
+  void BeginHold();
+  std::vector<std::pair<size_t, void*>> EndHold();
+  void ReturnHeld(std::vector<std::pair<size_t, void*>>* held);
+  bool holding() const { return holding_; }
   size_t bytes_in_use() const { return in_use_; }
   size_t bytes_pooled() const { return pooled_; }
 
@@ -97,6 +106,8 @@ class Runtime {
   int device_ = 0;
   hipStream_t stream_ = nullptr;
   std::multimap<size_t, void*> pool_;
+  std::multimap<size_t, void*> hold_pool_;
+  bool holding_ = false;
   size_t in_use_ = 0, pooled_ = 0;
   void* scratch_ = nullptr;
   size_t scratch_bytes_ = 0;

@@ -254,6 +254,9 @@ void InitZoneParams(const ProxOperatorArg& arg, ZoneParam* alpha, ZoneParam* bet
 
 class ScaledZoneProx final : public VectorProx {
  public:
+  bool CaptureSafe() const override { return true; }
+
+ public:
   void Init(const ProxOperatorArg& arg) override {
     VectorProx::Init(arg);
     const pb::ProxFunction& f = arg.prox_function();
@@ -397,6 +400,9 @@ REGISTER_EPIGRAPH_OPERATOR(SUM_QUANTILE, ScaledZoneEpigraph);
 // ---- Norm2Prox (reference prox/norm_2.cc:4-19) ---------------------------------------------------------
 
 class Norm2Prox final : public VectorProx {
+ public:
+  bool CaptureSafe() const override { return true; }
+
  protected:
   void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
     const DVec& v = input.value_vec(0);
@@ -422,6 +428,9 @@ REGISTER_PROX_OPERATOR(NORM_2, Norm2Prox);
 // ---- NonNegativeProx (reference prox/non_negative.cc:3-11) ---------------------------------------------
 
 class NonNegativeProx final : public VectorProx {
+ public:
+  bool CaptureSafe() const override { return true; }
+
  protected:
   void ApplyVector(const VectorProxInput& input, VectorProxOutput* output) override {
     const DVec& v = input.value_vec(0);
@@ -448,6 +457,9 @@ REGISTER_PROX_OPERATOR(TOTAL_VARIATION_1D, TotalVariation1DProx);
 // ---- SumSquareProx: ||H(x)||_2^2 (reference prox/sum_square.cc:10-40) ---------------------------------
 
 class SumSquareProx final : public ProxOperator {
+ public:
+  bool CaptureSafe() const override { return true; }
+
  public:
   void Init(const ProxOperatorArg& arg) override {
     const BlockMatrix& H = arg.affine_arg().A;
@@ -553,6 +565,9 @@ REGISTER_EPIGRAPH_OPERATOR(SUM_SQUARE, SumSquareEpigraph);
 
 class ZeroProx final : public ProxOperator {
  public:
+  bool CaptureSafe() const override { return true; }
+
+ public:
   void Init(const ProxOperatorArg& arg) override {
     const BlockMatrix& H = arg.affine_arg().A;
     const BlockVector& g = arg.affine_arg().b;
@@ -576,6 +591,9 @@ REGISTER_PROX_OPERATOR(ZERO, ZeroProx);
 // ---- AffineProx: c'x (reference prox/affine.cc:8-49) ---------------------------------------------------
 
 class AffineProx final : public ProxOperator {
+ public:
+  bool CaptureSafe() const override { return true; }
+
  public:
   void Init(const ProxOperatorArg& arg) override {
     const BlockMatrix& A = arg.affine_constraint().A;

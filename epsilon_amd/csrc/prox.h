@@ -57,6 +57,10 @@ class ProxOperator {  // reference prox/prox.h:37-43
   virtual BlockVector Apply(const BlockVector& v) = 0;
   virtual bool DescribeLeastSquares(LeastSquaresDesc* d) const { return false; }
   virtual bool DescribeScaledZone(ScaledZoneDesc* d) const { return false; }
+  // true: Apply is a fixed sequence of launches on the library's stream - no host
+  // synchronisation, no decision on device data, no state carried from one call to the next -
+  // so a sweep through this operator can be captured into a hipGraph and replayed (admm.cc).
+  virtual bool CaptureSafe() const { return false; }
 };
 
 std::unique_ptr<ProxOperator> CreateProxOperator(int type, bool epigraph);

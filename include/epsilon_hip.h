@@ -82,7 +82,11 @@ const char* eps_version(void);
  * each) and adds 1 / 2 / 3 refinement steps (residual against the blocks as given) above
  * 1e3 / 3e4 / 3e6; below 1e3 - every BASELINE.json lasso - the solve is the reference's
  * sequence of operations unchanged.
- * "0" switches it off (env EPSILON_HIP_REFINE). */
+ * "0" switches it off (env EPSILON_HIP_REFINE).
+ * "graph_generic" = "0" (default) | "1" | "2"  replay the sweeps of the generic operator path
+ * between two residual checks from a hipGraph (1: once a run has lasted 50 sweeps, 2: from the
+ * second sweep on); bit-identical to eager launches and, as measured, no faster (env
+ * EPSILON_HIP_GRAPH_GENERIC). */
 int eps_set_option(const char* key, const char* value);
 /* Number of visible HIP devices (0 if none); never fails. */
 int eps_device_count(void);
@@ -195,6 +199,11 @@ int eps_shard_consensus_terms(int on);
  * factorisations set up since the last reset (fp32 mode; see the "refine" option).  Either
  * pointer may be NULL; reset != 0 clears the record afterwards.  Diagnostics / tests. */
 int eps_block_solve_stats(double* max_condition, int* max_refine_steps, int reset);
+
+/* Sweeps of the generic operator path that were replayed from a captured hipGraph, and the
+ * captures made, since the last reset (EPSILON_HIP_GRAPH_GENERIC=0 turns the replay off).
+ * Either pointer may be NULL.  Diagnostics / tests. */
+int eps_graph_stats(long long* replayed_sweeps, long long* captures, int reset);
 
 /* ---- live kernel timing ---------------------------------------------------------------------- */
 /* When enabled, every hot kernel launch is bracketed by HIP events on the solver's stream.

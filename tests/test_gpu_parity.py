@@ -652,6 +652,45 @@ def test_more_benchmark_problems(solve_mod, dtype, name):
         np.testing.assert_allclose(np.frombuffer(xg[k]), np.frombuffer(xo[k]), err_msg=k, **tol)
 
 
+@pytest.mark.parametrize("name,solver_id", [("mv_lasso", 0), ("hinge_l1", 0), ("group_lasso", 0), ("lp", 0),
+                                            ("least_abs_dev", 0), ("mv_lasso", 1), ("hinge_l1", 1)])
+def test_generic_path_graph_replay_is_bit_identical(solve_mod, dtype, name, solver_id):
+    """The sweeps of the generic operator path between two residual checks CAN be replayed from one
+    hipGraph (admm.cc: canonical state buffers, copies back at the end of the captured batch, a
+    buffer hold around everything the capture touches; off by default - it measured no faster than
+    eager launches): the same kernels with the same arguments, so the iterates, the residuals and
+    the stopping sweep are those of the eager launches, bit for bit; the replay must really have
+    happened."""
+    import os
+    prob, info = {"mv_lasso": lambda: problems.mv_lasso(30, 40, 3, rho=0.1),
+                  "hinge_l1": lambda: problems.hinge_l1(40, 10),
+                  "group_lasso": lambda: problems.group_lasso(30, 20, 3),
+                  "lp": lambda: problems.lp(20, 8),
+                  "least_abs_dev": lambda: problems.least_abs_dev(30, 5)}[name]()
+    pb, data = prob.SerializeToString(), prob.expression_data()
+    # (the graph is built once a run has lasted 50 sweeps: batches of 10 and a ragged last one follow)
+    sb = wire.SolverParams(max_iterations=135, solver=solver_id, ignore_stopping_criteria=True).SerializeToString()
+    solve_mod.set_option("dtype", dtype)
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            solve_mod.set_option("graph_generic", mode)
+            solve_mod.graph_stats(reset=True)
+            st, x = solve_mod.solve(pb, [], sb, data)
+            out[mode] = (wire.SolverStatus.FromString(st), x, solve_mod.graph_stats())
+    finally:
+        solve_mod.set_option("graph_generic", "0")
+        solve_mod.set_option("dtype", "f32")
+    (sg, xg, (replayed, captures)), (se, xe, (replayed_e, _)) = out["1"], out["0"]
+    assert replayed_e == 0
+    assert replayed >= 20 and captures >= 1, (replayed, captures)
+    assert sg.num_iterations == se.num_iterations and sg.state == se.state
+    for f in ("r_norm", "s_norm", "epsilon_primal", "epsilon_dual"):
+        assert getattr(sg.residuals, f) == getattr(se.residuals, f), f
+    for k in xe:
+        assert xg[k] == xe[k], k
+
+
 def test_error_reporting(solve_mod):
     """A failed CHECK surfaces as _solve.error with a message (reference: longjmp ->
     _solve.error("CHECK failed"), solvemodule.cc:245-248)."""
