@@ -602,6 +602,67 @@ __global__ __launch_bounds__(kBlock) void GemmMfmaF64Kernel(
   }
 }
 
+// ---- small products ---------------------------------------------------------------------------------
+// A product whose result fits a handful of 128 x 128 tiles (the 100 x 100 factors of the
+// reference's robust-PCA benchmark, the panels of a small SVD) ran on ONE workgroup of the
+// matrix-core kernel: 22 us for 100-cubed, prologue and latency, not arithmetic.  Here every
+// 32 x 32 block of the result is a workgroup (16 of them at 100 x 100), k in chunks of 32 through
+// LDS, a 2 x 2 block per thread, the sums in plain ascending-k order.
+template <class T>
+__global__ __launch_bounds__(256) void GemmSmallKernel(int tA, int tB, int64_t M, int64_t N, int64_t K, T alpha,
+                                                       const T* __restrict__ A, int64_t lda,
+                                                       const T* __restrict__ B, int64_t ldb, T beta, T* C,
+                                                       int64_t ldc) {
+  __shared__ T As[32][33], Bs[32][33];  // [k][i], [k][j]
+  const int64_t i0 = static_cast<int64_t>(blockIdx.x) * 32, j0 = static_cast<int64_t>(blockIdx.y) * 32;
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  T acc[2][2] = {{T(0), T(0)}, {T(0), T(0)}};
+  for (int64_t k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = t + 256 * e;
+      {  // op(A)(i, k): A[i + k lda] (lanes along i) or A[k + i lda] (lanes along k)
+        const int ii = tA ? idx >> 5 : idx & 31, kk = tA ? idx & 31 : idx >> 5;
+        const int64_t i = i0 + ii, k = k0 + kk;
+        As[kk][ii] = (i < M && k < K) ? (tA ? A[k + i * lda] : A[i + k * lda]) : T(0);
+      }
+      {  // op(B)(k, j): B[k + j ldb] (lanes along k) or B[j + k ldb] (lanes along j)
+        const int kk = tB ? idx >> 5 : idx & 31, jj = tB ? idx & 31 : idx >> 5;
+        const int64_t k = k0 + kk, j = j0 + jj;
+        Bs[kk][jj] = (k < K && j < N) ? (tB ? B[j + k * ldb] : B[k + j * ldb]) : T(0);
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const T a0 = As[kk][2 * tx], a1 = As[kk][2 * tx + 1], b0 = Bs[kk][2 * ty], b1 = Bs[kk][2 * ty + 1];
+      acc[0][0] += a0 * b0;
+      acc[1][0] += a1 * b0;
+      acc[0][1] += a0 * b1;
+      acc[1][1] += a1 * b1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int64_t i = i0 + 2 * tx + a, j = j0 + 2 * ty + b;
+      if (i >= M || j >= N) continue;
+      T* c = C + i + j * ldc;
+      const T v = alpha * acc[a][b];
+      *c = (beta == T(0)) ? v : v + beta * (*c);
+    }
+}
+
+bool SmallGemmWanted(int64_t M, int64_t N, int64_t K) {
+  static const bool off = [] {
+    const char* e = std::getenv("EPSILON_HIP_GEMM_SMALL");
+    return e && e[0] == '0';
+  }();
+  return !off && M >= 1 && N >= 1 && M <= 256 && N <= 256 && K <= 4096;
+}
+
 int GemmMode() {  // 0 auto, 1 generic, 2 mfma, 3 mfma without the pipelined kernel
   // (read on every call: eps_set_option("gemm", ...) switches it between products in the tests)
   const char* e = std::getenv("EPSILON_HIP_GEMM");
@@ -630,6 +691,26 @@ void Gemm(bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alph
   if (!transB && !lower_only && N <= 16 && M * K >= (int64_t(1) << 18) &&
       MultiGemv(transA, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc))
     return;
+  if (!lower_only && GemmMode() == 0 && SmallGemmWanted(M, N, K)) {
+    EPS_CHECK(A.dt == B.dt && A.dt == C.dt);
+    const int64_t a_rows = transA ? K : M, a_cols = transA ? M : K, b_rows = transB ? N : K, b_cols = transB ? K : N;
+    EPS_CHECK_MSG(lda >= a_rows && ldb >= b_rows && ldc >= M, "gemm: bad leading dimension");
+    EPS_CHECK_MSG(K == 0 || (A.n >= (a_cols - 1) * lda + a_rows && B.n >= (b_cols - 1) * ldb + b_rows),
+                  "gemm: operand buffer too small");
+    EPS_CHECK_MSG(C.n >= (N - 1) * ldc + M, "gemm: C buffer too small");
+    ProfScope prof("gemm_small", M * N, K);
+    const dim3 grid(static_cast<unsigned>((M + 31) / 32), static_cast<unsigned>((N + 31) / 32));
+    hipStream_t st = Runtime::Get().stream();
+    if (A.dt == F32)
+      hipLaunchKernelGGL(GemmSmallKernel<float>, grid, dim3(256), 0, st, transA ? 1 : 0, transB ? 1 : 0, M, N, K,
+                         static_cast<float>(alpha), A.as<float>(), lda, B.as<float>(), ldb, static_cast<float>(beta),
+                         C.as<float>(), ldc);
+    else
+      hipLaunchKernelGGL(GemmSmallKernel<double>, grid, dim3(256), 0, st, transA ? 1 : 0, transB ? 1 : 0, M, N, K,
+                         alpha, A.as<double>(), lda, B.as<double>(), ldb, beta, C.as<double>(), ldc);
+    EPS_HIP(hipGetLastError());
+    return;
+  }
   const int64_t tiles = ((M + MT - 1) / MT) * ((N + MT - 1) / MT);
   if (!lower_only && tiles <= 64 && K >= 8192 && M > 0 && N > 0) {
     int64_t nsplit = std::min<int64_t>(K / 2048, 512 / tiles);
