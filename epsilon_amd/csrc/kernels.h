@@ -45,6 +45,12 @@ void Gemv(bool trans, int64_t rows, int64_t cols, double alpha, const DVec& A, i
 void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, double beta,
           const DVec& y, const DVec* work = nullptr);
 int64_t SymvWorkspace(int64_t n);
+// The same apply from a tile-packed copy of the lower tiles (every 128 x 128 tile contiguous,
+// zero-padded at the edge): SymvPack builds it once (SymvPackedSize(n) values), SymvPacked applies it.
+int64_t SymvPackedSize(int64_t n);
+DVec SymvPack(int64_t n, const DVec& S, int64_t lds);
+void SymvPacked(int64_t n, double alpha, const DVec& P, const DVec& x, double beta, const DVec& y,
+                const DVec* work = nullptr);
 
 // y[r] = alpha * sum_{k < nparts} partial[k*rows + r] + beta*y[r], fixed summation order.
 // `add` (optional) is added to the result afterwards: y = (alpha*sum + beta*y) + add.

@@ -403,7 +403,10 @@ void LaunchGemvT(int64_t rows, int64_t cols, double alpha, const T* A, int64_t l
 // ------------------------------------------------------------------------------------------
 constexpr int kSB = 128;
 
-template <class T>
+// PACKED: S is the tile-packed copy made by SymvPack - tile `lin` is 128 x 128 values, column-major,
+// contiguous (64 KB in f32), zero-padded at the matrix edge: a workgroup's 64 KB then come out of
+// a few DRAM pages instead of 128 column pieces of 512 bytes each 4 lds bytes apart.
+template <class T, bool PACKED>
 __global__ __launch_bounds__(kBlock) void SymvTileKernel(int64_t n, const T* __restrict__ S,
                                                          int64_t lds, const T* __restrict__ x,
                                                          T* __restrict__ prow,
@@ -428,8 +431,8 @@ __global__ __launch_bounds__(kBlock) void SymvTileKernel(int64_t n, const T* __r
   // thread (rg, cg): rows 4*(rg + 8q) + v (q, v < 4) of columns cg + 32k (k < 4).  Column sums
   // then need only 3 shuffle steps over the 8 row groups; row sums go through LDS.
   const int rg = t & 7, cg = t >> 3;
-  const bool full = (i0 + kSB <= n) && (j0 + kSB <= n) && (lds % 4 == 0) &&
-                    (reinterpret_cast<uintptr_t>(S) % 16 == 0);
+  const bool full = PACKED || ((i0 + kSB <= n) && (j0 + kSB <= n) && (lds % 4 == 0) &&
+                               (reinterpret_cast<uintptr_t>(S) % 16 == 0));
   T a[4][4][4];  // [k][q][v]
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(kBlock) void SymvTileKernel(int64_t n, const T* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = 4 * (rg + 8 * q);
-      const T* src = S + (i0 + r) + (j0 + c) * lds;
+      const T* src = PACKED ? S + lin * (kSB * kSB) + r + c * kSB : S + (i0 + r) + (j0 + c) * lds;
       if (full) {
         if constexpr (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(a[k][q]) = *reinterpret_cast<const float4*>(src);
@@ -527,7 +530,22 @@ __global__ __launch_bounds__(kBlock) void SymvReduceKernel(int64_t n, int64_t nb
   }
 }
 
+// tile-packed copy of the lower tiles of a symmetric matrix (see SymvTileKernel<T, true>)
 template <class T>
+__global__ __launch_bounds__(kBlock) void SymvPackKernel(int64_t n, const T* __restrict__ S, int64_t lds,
+                                                         T* __restrict__ P) {
+  const int64_t lin = blockIdx.x;
+  int64_t I = static_cast<int64_t>((sqrt(8.0 * static_cast<double>(lin) + 1.0) - 1.0) * 0.5);
+  while ((I + 1) * (I + 2) / 2 <= lin) ++I;
+  while (I * (I + 1) / 2 > lin) --I;
+  const int64_t J = lin - I * (I + 1) / 2, i0 = I * kSB, j0 = J * kSB;
+  for (int e = threadIdx.x; e < kSB * kSB; e += kBlock) {
+    const int r = e & (kSB - 1), c = e >> 7;  // kSB == 128
+    P[lin * (kSB * kSB) + e] = (i0 + r < n && j0 + c < n) ? S[(i0 + r) + (j0 + c) * lds] : T(0);
+  }
+}
+
+template <class T, bool PACKED = false>
 void LaunchSymv(int64_t n, double alpha, const T* S, int64_t lds, const T* x, double beta, T* y,
                 void* work) {
   Runtime& rt = Runtime::Get();
@@ -541,7 +559,7 @@ void LaunchSymv(int64_t n, double alpha, const T* S, int64_t lds, const T* x, do
   }
   T* prow = static_cast<T*>(work);
   T* pcol = prow + ntiles * kSB;
-  hipLaunchKernelGGL((SymvTileKernel<T>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, s,
+  hipLaunchKernelGGL((SymvTileKernel<T, PACKED>), dim3(static_cast<unsigned>(ntiles)), dim3(kBlock), 0, s,
                      n, S, lds, x, prow, pcol);
   static_assert(kSB == 128 && kBlock == 256, "SymvReduceKernel geometry");
   hipLaunchKernelGGL((SymvReduceKernel<T>), dim3(static_cast<unsigned>(nb)), dim3(kBlock), 0, s, n,
@@ -566,6 +584,38 @@ void Symv(int64_t n, double alpha, const DVec& S, int64_t lds, const DVec& x, do
   void* wp = work ? work->data() : nullptr;
   if (S.dt == F32) LaunchSymv<float>(n, alpha, S.as<float>(), lds, x.as<float>(), beta, y.as<float>(), wp);
   else LaunchSymv<double>(n, alpha, S.as<double>(), lds, x.as<double>(), beta, y.as<double>(), wp);
+  EPS_HIP(hipGetLastError());
+}
+
+int64_t SymvPackedSize(int64_t n) {
+  const int64_t nb = (n + kSB - 1) / kSB;
+  return nb * (nb + 1) / 2 * kSB * kSB;
+}
+
+DVec SymvPack(int64_t n, const DVec& S, int64_t lds) {
+  EPS_CHECK(lds >= n && (n == 0 || S.n >= (n - 1) * lds + n));
+  DVec P = DVec::Empty(SymvPackedSize(n), S.dt);
+  if (n == 0) return P;
+  const int64_t nb = (n + kSB - 1) / kSB;
+  const unsigned tiles = static_cast<unsigned>(nb * (nb + 1) / 2);
+  hipStream_t s = Runtime::Get().stream();
+  if (S.dt == F32)
+    hipLaunchKernelGGL(SymvPackKernel<float>, dim3(tiles), dim3(kBlock), 0, s, n, S.as<float>(), lds, P.as<float>());
+  else
+    hipLaunchKernelGGL(SymvPackKernel<double>, dim3(tiles), dim3(kBlock), 0, s, n, S.as<double>(), lds, P.as<double>());
+  EPS_HIP(hipGetLastError());
+  return P;
+}
+
+void SymvPacked(int64_t n, double alpha, const DVec& P, const DVec& x, double beta, const DVec& y, const DVec* work) {
+  EPS_CHECK(P.dt == x.dt && P.dt == y.dt && x.n == n && y.n == n && P.n >= SymvPackedSize(n));
+  EPS_CHECK_MSG(x.data() != y.data(), "symv: x and y alias");
+  if (n == 0) return;
+  if (work) EPS_CHECK(work->dt == P.dt && work->n >= SymvWorkspace(n));
+  ProfScope prof("symv_packed", n);
+  void* wp = work ? work->data() : nullptr;
+  if (P.dt == F32) LaunchSymv<float, true>(n, alpha, P.as<float>(), kSB, x.as<float>(), beta, y.as<float>(), wp);
+  else LaunchSymv<double, true>(n, alpha, P.as<double>(), kSB, x.as<double>(), beta, y.as<double>(), wp);
   EPS_HIP(hipGetLastError());
 }
 
