@@ -226,6 +226,10 @@ class DenseMatrixImpl final : public LinearMapImpl {  // linear/dense_matrix_imp
   double scale_;
   uint64_t id_;
   bool symmetric_;
+  // a symmetric map that is applied again and again (a cached inverse inside the sweeps) gets a
+  // tile-packed copy of its lower tiles for the apply (kernels_gemv.hip: SymvPacked)
+  mutable DVec packed_;
+  mutable int applies_ = 0;
 };
 
 // Memo of dense setup results (Gram products, sums, explicit inverses) keyed by content id.
