@@ -362,6 +362,73 @@ __global__ __launch_bounds__(kThreads, 2) void GemmSplitF16Kernel(
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS
     }
+    // Epilogue of an interior tile through LDS: the accumulator layout gives a store instruction
+    // 32 consecutive rows of two columns (128-byte pieces, 4 bytes per lane, 128 instructions per
+    // wave) - with a rank-256 update of the Cholesky trailing matrix, where the old C is read as
+    // well, the epilogue IS the kernel.  Staged through the (now idle) ring, half a tile at a time
+    // ([column][row], 128 KB), a wave instead moves whole 1 KB column pieces, 16 bytes per lane: a
+    // quarter of the memory instructions, and 8 consecutive lines of a DRAM page per piece.  The
+    // value written is the same expression as below, bit for bit.
+    const bool interior = P == nullptr && i0 + TS <= M && j0 + TS <= N && ldc % 4 == 0 &&
+                          reinterpret_cast<uintptr_t>(C) % 16 == 0;
+    if (interior) {
+      float* stage = reinterpret_cast<float*>(&ring[0][0][0]);  // 128 columns x 256 rows
+      const int row4 = lane * 4;
+      float ui[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ui[e] = SplitScaleInv(oa.rowmax[i0 + row4 + e]);
+      __syncthreads();  // every wave has left the main loop: the ring is free
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        if ((wj >> 1) == h) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int col = (wj & 1) * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                stage[col * TS + wi * 128 + a * 32 + l31] = acc[a][b][r];
+              }
+        }
+        __syncthreads();
+        // wave w: columns w, w + 8, ... of this half; lane: rows 4 lane .. 4 lane + 3.  The old
+        // values in batches of 8 independent loads ahead of their stores (C may alias nothing
+        // here, but the compiler cannot know: a load behind a store would wait for it)
+#pragma unroll 1
+        for (int qb = 0; qb < 16; qb += 8) {
+          float4 old[8];
+          if (beta != 0.0f) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int64_t j = j0 + h * 128 + wave + 8 * (qb + q);
+              old[q] = *reinterpret_cast<const float4*>(C + i0 + row4 + j * ldc);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int c = wave + 8 * (qb + q);
+            const int64_t j = j0 + h * 128 + c;
+            const float uj = SplitScaleInv(ob.rowmax[j]);
+            const float4 a4 = *reinterpret_cast<const float4*>(stage + c * TS + row4);
+            float4 v;
+            v.x = alpha * ((ui[0] * a4.x) * uj);
+            v.y = alpha * ((ui[1] * a4.y) * uj);
+            v.z = alpha * ((ui[2] * a4.z) * uj);
+            v.w = alpha * ((ui[3] * a4.w) * uj);
+            if (beta != 0.0f) {
+              v.x = v.x + beta * old[q].x;
+              v.y = v.y + beta * old[q].y;
+              v.z = v.z + beta * old[q].z;
+              v.w = v.w + beta * old[q].w;
+            }
+            *reinterpret_cast<float4*>(C + i0 + row4 + j * ldc) = v;
+          }
+        }
+        __syncthreads();  // the next half overwrites the stage
+      }
+      return;
+    }
   } else if constexpr (V >= 1) {
     // two buffers x (H_I, L_I, H_J, L_J) x 256 rows x 64 bytes = 128 KB.  A wave-instruction of
     // the LDS-DMA writes 64 x 16 bytes contiguously (16 rows), so the image is the global slab's
