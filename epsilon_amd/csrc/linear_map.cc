@@ -421,12 +421,13 @@ bool DenseMatrixImpl::Equals(const LinearMapImpl& o) const {
 }
 void DenseMatrixImpl::Apply(double alpha, const DVec& x, double beta, const DVec& y) const {
   if (symmetric_ && rows_ >= 1024) {  // half the bytes; below that the two launches cost more
-    static const bool packed = [] {
-      const char* e = std::getenv("EPSILON_HIP_SYMV_PACKED");
-      return !(e && e[0] == '0');
-    }();
     // from the third apply on from a tile-packed copy (+ rows^2 / 2 values): 41 -> 31 us at 1e4
-    if (packed && packed_.n == 0 && ++applies_ >= 3 && !Runtime::Get().capturing())
+    // (EPSILON_HIP_SYMV_PACKED=0: never; =2: from the first apply - tests; read per call)
+    const char* e = std::getenv("EPSILON_HIP_SYMV_PACKED");
+    const bool packed = !(e && e[0] == '0');
+    const int first = (e && e[0] == '2') ? 1 : 3;
+    if (!packed) packed_ = DVec();
+    if (packed && packed_.n == 0 && ++applies_ >= first && !Runtime::Get().capturing())
       packed_ = k::SymvPack(rows_, data_, rows_);
     if (packed_.n > 0) k::SymvPacked(rows_, alpha * scale_, packed_, x, beta, y);
     else k::Symv(rows_, alpha * scale_, data_, rows_, x, beta, y);

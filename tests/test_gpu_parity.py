@@ -206,6 +206,22 @@ def test_cached_inverse_apply_symmetric_kernel(solve_mod, dtype, n):
     want = np.linalg.solve(W, x)
     tol = dict(rtol=1e-9, atol=1e-10) if dtype == "f64" else dict(rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(got, want, **tol)
+    # ... and from the tile-packed copy of the lower tiles that a repeatedly applied symmetric map
+    # gets (every 128 x 128 tile contiguous, zero-padded at the edge): the same arithmetic in the
+    # same order, so the same bits
+    import os
+    saved = os.environ.get("EPSILON_HIP_SYMV_PACKED")
+    try:
+        os.environ["EPSILON_HIP_SYMV_PACKED"] = "2"
+        packed = solve_mod.linear_map_apply(ir.dense_matrix(W), x, inverse=True)
+        os.environ["EPSILON_HIP_SYMV_PACKED"] = "0"
+        plain = solve_mod.linear_map_apply(ir.dense_matrix(W), x, inverse=True)
+    finally:
+        if saved is None:
+            os.environ.pop("EPSILON_HIP_SYMV_PACKED", None)
+        else:
+            os.environ["EPSILON_HIP_SYMV_PACKED"] = saved
+    assert np.array_equal(packed, plain) and np.array_equal(plain, got)
 
 
 def test_gemm_mfma_vs_oracle(solve_mod):
