@@ -505,3 +505,67 @@ def lp(m, n, seed=0):
         return [ir.prox(ProxFunction.AFFINE, ir.linear_map(ir.dense_matrix(c.reshape(1, -1)), x)),
                 ir.prox(ProxFunction.NON_NEGATIVE, s)]
     return _graph_form(terms, -A, b, z_key="var:s"), dict(A=A, b=b, c=c)
+
+
+# ---- the reference's solver-level known answers (python/epopt/constant_atoms_test.py) ------------
+
+def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None):
+    """minimise f(x)  s.t.  x - c = 0  for ONE prox function f of this path: the hand-compiled form
+    of the reference's "atoms with variable arguments" test (constant_atoms_test.py:283-292: one
+    variable per argument, tied to the constant by an equality constraint).  `arg_columns` is the
+    constant as CVXPY reads a literal: a list of columns.  Returns (problem, c) with c the m x n
+    constant."""
+    c = np.array(arg_columns, dtype=np.float64).T
+    if c.ndim == 1:
+        c = c.reshape(-1, 1)
+    m, n = c.shape
+    x = ir.variable(m, n, "var:x")
+    kw = {}
+    if k is not None:
+        kw["sum_largest_params"] = wire.SumLargestParams(k=int(k))
+    if alpha is not None:
+        a, b = ir.constant(np.full(m * n, float(alpha))), ir.constant(np.full(m * n, float(beta)))
+        data = dict(a.data)
+        data.update(b.data)
+        kw["scaled_zone_params"] = wire.ProxScaledZoneParams(alpha_expr=a.proto, beta_expr=b.proto)
+        kw["data"] = data
+    f = ir.prox(getattr(ProxFunction, prox_name), x, alpha=1.0, **kw)
+    con = ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, m * n), ir.constant(c.reshape(-1, 1, order="F")))))
+    return ir.Problem([f], [con]), c
+
+
+def constant_atom_value(prox_name, X, k=None, alpha=None, beta=None):
+    """f(X) in numpy, for the objective the reference's test evaluates at the returned variable."""
+    X = np.asarray(X, dtype=np.float64)
+    v = X.reshape(-1, order="F")
+    if prox_name == "NORM_1":
+        return float(np.abs(v).sum())
+    if prox_name == "NORM_2":
+        return float(np.sqrt((v ** 2).sum()))
+    if prox_name == "NORM_NUCLEAR":
+        return float(np.linalg.svd(X, compute_uv=False).sum())
+    if prox_name == "LAMBDA_MAX":
+        return float(np.linalg.eigvalsh(0.5 * (X + X.T)).max())
+    if prox_name == "SUM_SQUARE":
+        return float((v ** 2).sum())
+    if prox_name == "TOTAL_VARIATION_1D":
+        return float(np.abs(np.diff(v)).sum())
+    if prox_name == "MAX":
+        return float(v.max())
+    if prox_name == "SUM_LARGEST":
+        return float(np.sort(v)[::-1][:k].sum())
+    if prox_name == "LOG_SUM_EXP":
+        return float(np.log(np.exp(v - v.max()).sum()) + v.max())
+    if prox_name == "SUM_EXP":
+        return float(np.exp(v).sum())
+    if prox_name == "SUM_INV_POS":
+        return float((1.0 / v).sum())
+    if prox_name == "SUM_HINGE":
+        return float(np.maximum(v, 0).sum())
+    if prox_name == "SUM_QUANTILE":
+        return float((alpha * np.maximum(v, 0) + beta * np.maximum(-v, 0)).sum())
+    if prox_name == "SUM_NEG_LOG":
+        return float(-np.log(v).sum())
+    if prox_name == "NEG_LOG_DET":
+        return float(-np.linalg.slogdet(0.5 * (X + X.T))[1])
+    raise ValueError(prox_name)

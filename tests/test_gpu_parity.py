@@ -7,6 +7,8 @@ stated fp32 tolerance.  Projection / threshold outputs are compared exactly wher
 operands are exactly representable.
 """
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -705,6 +707,40 @@ def test_generic_path_graph_replay_is_bit_identical(solve_mod, dtype, name, solv
         assert getattr(sg.residuals, f) == getattr(se.residuals, f), f
     for k in xe:
         assert xg[k] == xe[k], k
+
+
+def _atom_cases():
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                    "reference_known_answers.json")))["constant_atoms"]
+    return g, g["cases"]
+
+
+@pytest.mark.parametrize("solver_id", [0, 1])
+def test_reference_constant_atom_known_answers(solve_mod, dtype, solver_id):
+    """The reference's own solver-level known answers (python/epopt/constant_atoms_test.py: the
+    objective of `minimise atom(x) s.t. x == constant` at the returned variable must be the atom's
+    value at the constant within 1e-2 relative to 1 + |value|; rel_tol 1e-3, max_iterations 10000)
+    for every atom that is one prox function of this path - 33 cases, through the C ABI, both
+    drivers, both arithmetic types - and the same stopping sweep as the oracle."""
+    g, cases = _atom_cases()
+    sp = wire.SolverParams(rel_tol=g["rel_tol"], max_iterations=g["max_iterations"], solver=solver_id)
+    solve_mod.set_option("dtype", dtype)
+    try:
+        for case in cases:
+            kw = {k: case[k] for k in ("k", "alpha", "beta") if k in case}
+            prob, c = problems.constant_atom(case["prox"], case["arg"], **kw)
+            sg, xg, so, xo = solve_both(solve_mod, prob, sp)
+            assert sg.state == wire.SolverStatus.OPTIMAL, case
+            X = np.frombuffer(xg["var:x"]).reshape(c.shape, order="F")
+            val = problems.constant_atom_value(case["prox"], X, **kw)
+            if case.get("maximize"):
+                val = -val
+            assert abs(val - case["expected"]) / (1 + abs(case["expected"])) <= g["tolerance"], (case, val)
+            if dtype == "f64":
+                assert sg.num_iterations == so.num_iterations, (case, sg.num_iterations, so.num_iterations)
+    finally:
+        solve_mod.set_option("dtype", "f32")
 
 
 def test_error_reporting(solve_mod):

@@ -178,3 +178,27 @@ def test_lasso_elimination_order_fat_and_tall():
         M = (H + H.T()).scaled(alpha) + (A + A.T()) - H.left_identity() - A.left_identity()
         chol = BlockCholesky().compute(M)
         assert chol.p == expect
+
+
+_ATOMS = GOLDEN["constant_atoms"]
+
+
+@pytest.mark.parametrize("case", _ATOMS["cases"], ids=["%s-%d" % (c["prox"], i) for i, c in enumerate(_ATOMS["cases"])])
+def test_reference_constant_atom_known_answers(case):
+    """The reference's own solver-level known answers (python/epopt/constant_atoms_test.py:
+    minimise / maximise atom(x) s.t. x == constant; the objective at the returned variable must be
+    the atom's value at the constant within 1e-2 relative to 1 + |value|, solved with rel_tol 1e-3,
+    max_iterations 10000) for every atom that is one prox function of this path, through the
+    oracle's multi-block driver on the hand-compiled problem."""
+    from epsilon_amd import problems, wire
+    kw = {k: case[k] for k in ("k", "alpha", "beta") if k in case}
+    prob, c = problems.constant_atom(case["prox"], case["arg"], **kw)
+    sp_ = wire.SolverParams(rel_tol=_ATOMS["rel_tol"], max_iterations=_ATOMS["max_iterations"]).SerializeToString()
+    st, x = orc.solve(prob.SerializeToString(), [], sp_, prob.expression_data())
+    S = wire.SolverStatus.FromString(st)
+    assert S.state == wire.SolverStatus.OPTIMAL
+    X = np.frombuffer(x["var:x"]).reshape(c.shape, order="F")
+    val = problems.constant_atom_value(case["prox"], X, **kw)
+    if case.get("maximize"):
+        val = -val
+    assert abs(val - case["expected"]) / (1 + abs(case["expected"])) <= _ATOMS["tolerance"], (val, case["expected"])
