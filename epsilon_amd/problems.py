@@ -509,7 +509,7 @@ def lp(m, n, seed=0):
 
 # ---- the reference's solver-level known answers (python/epopt/constant_atoms_test.py) ------------
 
-def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None):
+def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None, arg_scale=None, linear=None):
     """minimise f(x)  s.t.  x - c = 0  for ONE prox function f of this path: the hand-compiled form
     of the reference's "atoms with variable arguments" test (constant_atoms_test.py:283-292: one
     variable per argument, tied to the constant by an equality constraint).  `arg_columns` is the
@@ -529,15 +529,25 @@ def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None):
         data.update(b.data)
         kw["scaled_zone_params"] = wire.ProxScaledZoneParams(alpha_expr=a.proto, beta_expr=b.proto)
         kw["data"] = data
-    f = ir.prox(getattr(ProxFunction, prox_name), x, alpha=1.0, **kw)
+    arg = x
+    if arg_scale is not None:  # f(arg_scale * x): neg(x) = pos(-x)
+        arg = ir.linear_map(ir.scalar(float(arg_scale), m * n), ir.reshape(x, m * n, 1))
+    if linear is not None:     # the AFFINE prox of a linear functional l^T vec(x) (sum_entries, trace)
+        arg = ir.linear_map(ir.dense_matrix(np.asarray(linear, dtype=np.float64).reshape(1, -1)),
+                            ir.reshape(x, m * n, 1))
+    f = ir.prox(getattr(ProxFunction, prox_name), arg, alpha=1.0, **kw)
     con = ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, m * n), ir.constant(c.reshape(-1, 1, order="F")))))
     return ir.Problem([f], [con]), c
 
 
-def constant_atom_value(prox_name, X, k=None, alpha=None, beta=None):
+def constant_atom_value(prox_name, X, k=None, alpha=None, beta=None, arg_scale=None, linear=None):
     """f(X) in numpy, for the objective the reference's test evaluates at the returned variable."""
     X = np.asarray(X, dtype=np.float64)
+    if arg_scale is not None:
+        X = arg_scale * X
     v = X.reshape(-1, order="F")
+    if prox_name == "AFFINE":
+        return float(np.dot(np.asarray(linear, dtype=np.float64), v))
     if prox_name == "NORM_1":
         return float(np.abs(v).sum())
     if prox_name == "NORM_2":
