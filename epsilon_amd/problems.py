@@ -509,7 +509,7 @@ def lp(m, n, seed=0):
 
 # ---- the reference's solver-level known answers (python/epopt/constant_atoms_test.py) ------------
 
-def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None, arg_scale=None, linear=None):
+def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None, arg_scale=None, linear=None, axis=None):
     """minimise f(x)  s.t.  x - c = 0  for ONE prox function f of this path: the hand-compiled form
     of the reference's "atoms with variable arguments" test (constant_atoms_test.py:283-292: one
     variable per argument, tied to the constant by an equality constraint).  `arg_columns` is the
@@ -529,6 +529,9 @@ def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None, arg_sca
         data.update(b.data)
         kw["scaled_zone_params"] = wire.ProxScaledZoneParams(alpha_expr=a.proto, beta_expr=b.proto)
         kw["data"] = data
+    if axis is not None:  # one value per column (axis 0) / row (axis 1), summed
+        kw["has_axis"] = True
+        kw["axis"] = int(axis)
     arg = x
     if arg_scale is not None:  # f(arg_scale * x): neg(x) = pos(-x)
         arg = ir.linear_map(ir.scalar(float(arg_scale), m * n), ir.reshape(x, m * n, 1))
@@ -540,7 +543,7 @@ def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None, arg_sca
     return ir.Problem([f], [con]), c
 
 
-def constant_atom_value(prox_name, X, k=None, alpha=None, beta=None, arg_scale=None, linear=None):
+def constant_atom_value(prox_name, X, k=None, alpha=None, beta=None, arg_scale=None, linear=None, axis=None):
     """f(X) in numpy, for the objective the reference's test evaluates at the returned variable."""
     X = np.asarray(X, dtype=np.float64)
     if arg_scale is not None:
@@ -548,6 +551,10 @@ def constant_atom_value(prox_name, X, k=None, alpha=None, beta=None, arg_scale=N
     v = X.reshape(-1, order="F")
     if prox_name == "AFFINE":
         return float(np.dot(np.asarray(linear, dtype=np.float64), v))
+    if axis is not None and prox_name == "MAX":
+        return float(X.max(axis=axis).sum())
+    if axis is not None and prox_name == "NORM_2":
+        return float(np.sqrt((X ** 2).sum(axis=axis)).sum())
     if prox_name == "NORM_1":
         return float(np.abs(v).sum())
     if prox_name == "NORM_2":

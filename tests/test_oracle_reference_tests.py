@@ -191,7 +191,7 @@ def test_reference_constant_atom_known_answers(case):
     max_iterations 10000) for every atom that is one prox function of this path, through the
     oracle's multi-block driver on the hand-compiled problem."""
     from epsilon_amd import problems, wire
-    kw = {k: case[k] for k in ("k", "alpha", "beta", "arg_scale", "linear") if k in case}
+    kw = {k: case[k] for k in ("k", "alpha", "beta", "arg_scale", "linear", "axis") if k in case}
     prob, c = problems.constant_atom(case["prox"], case["arg"], **kw)
     sp_ = wire.SolverParams(rel_tol=_ATOMS["rel_tol"], max_iterations=_ATOMS["max_iterations"]).SerializeToString()
     st, x = orc.solve(prob.SerializeToString(), [], sp_, prob.expression_data())
