@@ -538,6 +538,8 @@ def constant_atom(prox_name, arg_columns, k=None, alpha=None, beta=None, arg_sca
     if linear is not None:     # the AFFINE prox of a linear functional l^T vec(x) (sum_entries, trace)
         arg = ir.linear_map(ir.dense_matrix(np.asarray(linear, dtype=np.float64).reshape(1, -1)),
                             ir.reshape(x, m * n, 1))
+    if arg_scale is not None:
+        kw["arg_size"] = [(m, n)]  # (the scaled argument keeps the variable's shape)
     f = ir.prox(getattr(ProxFunction, prox_name), arg, alpha=1.0, **kw)
     con = ir.zero(ir.add(x, ir.linear_map(ir.scalar(-1, m * n), ir.constant(c.reshape(-1, 1, order="F")))))
     return ir.Problem([f], [con]), c
