@@ -721,7 +721,7 @@ def test_reference_constant_atom_known_answers(solve_mod, dtype, solver_id):
     """The reference's own solver-level known answers (python/epopt/constant_atoms_test.py: the
     objective of `minimise atom(x) s.t. x == constant` at the returned variable must be the atom's
     value at the constant within 1e-2 relative to 1 + |value|; rel_tol 1e-3, max_iterations 10000)
-    for every atom that is one prox function of this path - 63 cases, through the C ABI, both
+    for every atom that is one prox function of this path - 67 cases, through the C ABI, both
     drivers, both arithmetic types - and the same stopping sweep as the oracle."""
     g, cases = _atom_cases()
     sp = wire.SolverParams(rel_tol=g["rel_tol"], max_iterations=g["max_iterations"], solver=solver_id)
